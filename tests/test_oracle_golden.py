@@ -1,0 +1,184 @@
+"""Pin the CPU oracle against vectors recorded from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLD, load_golden, oracle_engine_for_case, oracle_model
+from oracle import ops, sequoia
+from oracle.model import AppendKV, SlotKV
+
+G = load_golden()
+OPS = np.load(os.path.join(GOLD, "ops.npz"))
+T = torch.from_numpy
+
+
+def test_reference_matches_hf_forward():
+    assert G["hf_vs_ref_max_abs"] < 1e-4
+    assert G["sequoia_3x4_equals_shipped"] is True
+
+
+def test_rope_matches_reference():
+    qe, ke = ops.apply_rope(T(OPS["rope_q"]), T(OPS["rope_k"]), T(OPS["rope_cos"]), T(OPS["rope_sin"]),
+                            T(OPS["rope_pos"]))
+    assert torch.equal(qe, T(OPS["rope_qe"])) and torch.equal(ke, T(OPS["rope_ke"]))
+
+
+def test_rope_tables_match_hf_inv_freq():
+    from umbrella_amd.models.config import LlamaCfg, rope_inv_freq
+    inv, scale = rope_inv_freq(LlamaCfg(**G["target_cfg"]))
+    ml = np.load(os.path.join(GOLD, "model_logits.npz"))
+    assert scale == 1.0
+    np.testing.assert_allclose(inv.numpy(), ml["inv_freq"], rtol=1e-6)
+
+
+def test_masked_attention_matches_reference_static_cache():
+    # StaticKV_Cache.compute_attention (cache.py:169-192) is HND; oracle is NHD
+    kc, vc = T(OPS["attn_kcache"]).clone(), T(OPS["attn_vcache"]).clone()     # [Hkv, Lmax, D]
+    sids = torch.arange(9, 16)
+    kc[:, sids] = T(OPS["attn_knew"]); vc[:, sids] = T(OPS["attn_vnew"])
+    q = T(OPS["attn_q"]).permute(1, 0, 2)                                       # [T, Hq, D]
+    out = ops.masked_attention(q, kc.permute(1, 0, 2), vc.permute(1, 0, 2), T(OPS["attn_mask"]))
+    torch.testing.assert_close(out, T(OPS["attn_out"]), rtol=1e-5, atol=1e-6)
+
+
+def test_kv_gather_matches_reference():
+    for cls in (AppendKV, SlotKV):
+        c = cls(1, 32, 2, 64, torch.float32)
+        c.k.copy_(T(OPS["gather_k_before"])); c.v.copy_(T(OPS["gather_v_before"]))
+        c.gather_kv_incremental(torch.tensor([9, 11, 14]), 9)
+        assert torch.equal(c.k, T(OPS["gather_k_after"])) and torch.equal(c.v, T(OPS["gather_v_after"]))
+        assert c.kv_offset == int(OPS["gather_offset"])
+
+
+def test_logit_helpers_match_reference():
+    lg, ids = T(OPS["rp_logits"]), T(OPS["rp_ids"])
+    assert torch.equal(ops.repetition_penalty(ids, lg, 1.05), T(OPS["rp_out"]))
+    assert torch.equal(ops.keep_topk(lg, 8), T(OPS["topk_out"]))
+    assert torch.equal(ops.topk_flatten_gather(lg[:3], 2, torch.tensor([0, 1, 2, 4])), T(OPS["argmax_gather"]))
+
+
+def test_sequoia_generator_kat():
+    with open(os.path.join(GOLD, "growmaps.json")) as f:
+        gm = json.load(f)
+    assert sequoia.generate(3, 4) == gm["3x4"]
+    assert sequoia.generate(5, 6, gm["5x6_acc"]) == gm["5x6"]
+
+
+def test_model_logits_match_reference():
+    ml = np.load(os.path.join(GOLD, "model_logits.npz"))
+    m = oracle_model(G["target_cfg"], G["seeds"]["target"], 128)
+    ids = T(ml["prompt"])[None]
+    n = ids.shape[1]
+    mask = torch.tril(torch.ones(n, 128, dtype=torch.bool))
+    logits = m.inference(ids, torch.arange(n)[None], mask, torch.arange(n))
+    np.testing.assert_allclose(logits[0, -1].numpy(), ml["logits_last"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logits[0, ::6, :64].numpy(), ml["logits_rows"], rtol=1e-4, atol=1e-4)
+
+
+def _replay(case_name):
+    case = G["cases"][case_name]
+    eng = oracle_engine_for_case(G, case_name)
+    ok = eng._prefill(torch.tensor([case["prompt"]]))
+    assert ok == case["prefill_ok"]
+    if not ok:
+        return
+    assert int(eng.tokens[0, eng.num_nodes]) == case["first_token"]
+    it_iter = iter(case["iters"])
+
+    def loop(turn):
+        start, go, steps = eng.num_nodes, True, 0
+        while go and (eng.num_nodes - start) < case["max_new_tokens"] and eng.validate_status():
+            n = eng.num_nodes
+            eng.build_tree()
+            rec = next(it_iter)
+            assert rec["n"] == n
+            assert eng.tokens[0, n:n + eng.tree_size].tolist() == rec["tree_tokens"], (case_name, steps)
+            assert eng.parents.tolist() == rec["parents"]
+            if "tree_score" in rec:
+                np.testing.assert_allclose(eng.tree_score.numpy(), np.array(rec["tree_score"]), rtol=1e-4, atol=1e-5)
+                cur = eng.cur
+                assert eng.mask_iter[n:cur, n:cur].sum(-1).tolist() == rec["tree_mask_rowsum"]
+            go = eng.verify()
+            assert eng.num_nodes == rec["num_nodes"] and go == rec["go_on"]
+            assert int(eng.tokens[0, eng.num_nodes]) == rec["bonus"]
+            assert eng.target_model.kv_cache.kv_offset == rec["target_kv"]
+            assert eng.draft_model.kv_cache.kv_offset == rec["draft_kv"]
+            steps += 1
+        assert eng.tokens[0, start:eng.num_nodes + 1].tolist() == turn["tokens"]
+        assert steps == turn["steps"]
+
+    loop(case["turns"][0])
+    if "append" in case:
+        assert eng._append(torch.tensor([case["append"]])) == case["append_ok"]
+        assert int(eng.tokens[0, eng.num_nodes]) == case["append_first_token"]
+        loop(case["turns"][1])
+    eng.reset()
+    toks, acc = eng.generate_ids(case["prompt"], case["max_new_tokens"])
+    assert toks == case["generate"]["generated_tokens"]
+    assert abs(acc - case["generate"]["avg_accept_tokens"]) < 1e-9
+
+
+@pytest.mark.parametrize("case", sorted(G["cases"].keys()))
+def test_engine_replays_reference_trace(case):
+    _replay(case)
+
+
+def test_greedy_spec_equals_greedy_ar():
+    """Property oracle: greedy speculative output == greedy AR output of the target."""
+    for case, key in (("static_3x4_selfdraft", "hf_greedy_prompt2"), ("static_3x4", "hf_greedy_prompt"),
+                      ("dynamic_w8b8d4_selfdraft", "hf_greedy_prompt2"), ("dynamic_w4b6d3", "hf_greedy_prompt")):
+        toks = G["cases"][case]["turns"][0]["tokens"]
+        ar = G[key]
+        n = min(len(toks), len(ar))
+        assert toks[:n] == ar[:n], case
+
+
+def test_accept_scan_synthetic_cases():
+    gm = sequoia.generate(3, 4)
+    mask = torch.tensor(gm["mask"]) == 1
+    want = mask.sum(-1)
+    parents = torch.zeros(13, dtype=torch.int32)
+    for v, s in enumerate(gm["Successors"]):
+        parents[s] = v
+    spec = torch.arange(100, 113)
+    # all reject: only the root; bonus = sampled[0]
+    sampled = torch.full((13,), 7)
+    path, bonus = ops.accept_scan(sampled, spec, parents, mask, want)
+    assert path.tolist() == [0] and bonus == 7
+    # full path 0 -> 1 -> 4 -> 7 -> 10
+    sampled = torch.full((13,), 7)
+    sampled[0], sampled[1], sampled[4], sampled[7], sampled[10] = 101, 104, 107, 110, 999
+    path, bonus = ops.accept_scan(sampled, spec, parents, mask, want)
+    assert path.tolist() == [0, 1, 4, 7, 10] and bonus == 999
+    # sibling (second child of root) matches, its child does not
+    sampled = torch.full((13,), 7)
+    sampled[0] = 102
+    path, bonus = ops.accept_scan(sampled, spec, parents, mask, want)
+    assert path.tolist() == [0, 2] and bonus == 7
+    # a deeper node "accepted" but its parent rejected must not be on the path
+    sampled = torch.full((13,), 7)
+    sampled[1] = 104
+    path, _ = ops.accept_scan(sampled, spec, parents, mask, want)
+    assert path.tolist() == [0]
+    assert ops.first_eos([5, 9, 3], [3, 9]) == 1 and ops.first_eos([5, 6], [3]) == -1
+
+
+def test_awq_pack_roundtrip_and_linear():
+    rs = np.random.RandomState(1)
+    q = rs.randint(0, 16, size=(256, 64)).astype(np.uint8)
+    assert np.array_equal(ops.awq_unpack(ops.awq_pack(q)), q)
+    # nibble i of word c <-> column 8c + ORDER[i]
+    one = np.zeros((1, 8), dtype=np.uint8); one[0, 2] = 0xF
+    assert ops.awq_pack(one).view(np.uint32)[0, 0] == 0xF << 4     # ORDER[1] == 2
+    z = rs.randint(0, 16, size=(2, 64)).astype(np.uint8)
+    s = (rs.rand(2, 64) * 0.02 + 0.005).astype(np.float16)
+    W = (q.astype(np.float32) - np.repeat(z, 128, 0)) * np.repeat(s.astype(np.float32), 128, 0)
+    x = torch.from_numpy(rs.randn(3, 256).astype(np.float32))
+    out = ops.awq_linear(x, T(ops.awq_pack(q)), T(ops.awq_pack(z)), T(s), 128)
+    torch.testing.assert_close(out, x @ torch.from_numpy(W.astype(np.float16).astype(np.float32)), rtol=1e-4, atol=1e-4)
+    from umbrella_amd.models.awq_format import pack_rows, unpack_rows
+    assert np.array_equal(pack_rows(q), ops.awq_pack(q)) and np.array_equal(unpack_rows(pack_rows(q)), q)

@@ -1,0 +1,129 @@
+"""Llama architecture descriptors and RoPE frequency tables.
+
+The reference resolves models by exact hub id through three dicts
+(umbrella/models/auto_model.py:9-182) and reads dims from
+``LlamaConfig.from_pretrained`` (umbrella/models/llama.py:24-33).  This box has
+no hub access, so the public dims of the BASELINE models are tabulated here;
+a local directory holding ``config.json`` is accepted as well.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+LLAMA3_ROPE = {"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
+               "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+LLAMA31_ROPE = dict(LLAMA3_ROPE, factor=8.0)
+
+
+@dataclass
+class LlamaCfg:
+    vocab_size: int = 128256
+    hidden_size: int = 2048
+    intermediate_size: int = 8192
+    num_hidden_layers: int = 16
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 64
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[dict] = None
+    max_position_embeddings: int = 131072
+    tie_word_embeddings: bool = False
+    eos_token_id: list = field(default_factory=lambda: [128001, 128008, 128009])
+    awq: bool = False                 # 4-bit AWQ (GEMM format, group 128, zero point)
+    awq_group: int = 128
+    name: str = "llama"
+
+    @property
+    def q_dim(self):
+        return self.num_attention_heads * self.head_dim
+
+    @property
+    def kv_dim(self):
+        return self.num_key_value_heads * self.head_dim
+
+    @classmethod
+    def from_dir(cls, path: str) -> "LlamaCfg":
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        rp = c.get("rope_parameters") or {}
+        rs = c.get("rope_scaling") or ({k: v for k, v in rp.items() if k != "rope_theta"} if rp.get("rope_type", "default") != "default" else None)
+        eos = c.get("eos_token_id", 2)
+        gen = os.path.join(path, "generation_config.json")
+        if os.path.exists(gen):                     # engines read eos from GenerationConfig (static:104-108)
+            with open(gen) as f:
+                eos = json.load(f).get("eos_token_id", eos)
+        q = c.get("quantization_config") or {}
+        return cls(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                   intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
+                   num_attention_heads=c["num_attention_heads"],
+                   num_key_value_heads=c.get("num_key_value_heads", c["num_attention_heads"]),
+                   head_dim=c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"],
+                   rms_norm_eps=c.get("rms_norm_eps", 1e-6),
+                   rope_theta=c.get("rope_theta") or rp.get("rope_theta", 10000.0), rope_scaling=rs,
+                   max_position_embeddings=c.get("max_position_embeddings", 8192),
+                   tie_word_embeddings=c.get("tie_word_embeddings", False),
+                   eos_token_id=eos if isinstance(eos, list) else [eos],
+                   awq=q.get("quant_method") == "awq", awq_group=q.get("group_size", 128),
+                   name=os.path.basename(os.path.normpath(path)))
+
+
+def _l(**kw):
+    return LlamaCfg(**kw)
+
+
+# Public HF configs of the hub ids the reference registers for Llama
+# (auto_model.py:9-154) and that BASELINE.json's configs name.
+KNOWN = {
+    "meta-llama/Llama-3.2-1B-Instruct": _l(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+        num_attention_heads=32, num_key_value_heads=8, head_dim=64, rope_scaling=LLAMA3_ROPE,
+        tie_word_embeddings=True, name="llama-3.2-1b"),
+    "meta-llama/Llama-3.1-8B-Instruct": _l(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+        num_attention_heads=32, num_key_value_heads=8, head_dim=128, rope_scaling=LLAMA31_ROPE, name="llama-3.1-8b"),
+    "hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4": _l(hidden_size=4096, intermediate_size=14336,
+        num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8, head_dim=128,
+        rope_scaling=LLAMA31_ROPE, awq=True, name="llama-3.1-8b-awq"),
+    "hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4": _l(hidden_size=8192, intermediate_size=28672,
+        num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8, head_dim=128,
+        rope_scaling=LLAMA31_ROPE, awq=True, name="llama-3.1-70b-awq"),
+    "casperhansen/llama-3.3-70b-instruct-awq": _l(hidden_size=8192, intermediate_size=28672,
+        num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8, head_dim=128,
+        rope_scaling=LLAMA31_ROPE, awq=True, name="llama-3.3-70b-awq"),
+}
+KNOWN["meta-llama/Llama-3.2-1B"] = KNOWN["meta-llama/Llama-3.2-1B-Instruct"]
+KNOWN["meta-llama/Meta-Llama-3.1-8B-Instruct"] = KNOWN["meta-llama/Llama-3.1-8B-Instruct"]
+
+
+def rope_inv_freq(cfg: LlamaCfg) -> tuple[torch.Tensor, float]:
+    """(inv_freq [D/2] fp32, attention_scaling).  Restates HF's default and
+    ``llama3`` rope initialisers, which is where the reference takes them from
+    (``hf_model.model.rotary_emb.inv_freq``, umbrella/models/llama.py:48-49)."""
+    D = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    rs = cfg.rope_scaling
+    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+        old = rs["original_max_position_embeddings"]
+        low_wl, high_wl = old / lo, old / hi
+        wl = 2 * math.pi / inv
+        inv_l = torch.where(wl > low_wl, inv / factor, inv)
+        smooth = (old / wl - lo) / (hi - lo)
+        smoothed = (1 - smooth) * inv_l / factor + smooth * inv_l
+        mid = ~(wl < high_wl) & ~(wl > low_wl)
+        inv = torch.where(mid, smoothed, inv_l)
+    return inv, 1.0
+
+
+def rope_tables(cfg: LlamaCfg, max_length: int, dtype) -> tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [Lmax, D] built in fp32 then cast to the model dtype
+    (umbrella/models/llama.py:50-60)."""
+    inv, scale = rope_inv_freq(cfg)
+    freqs = torch.outer(torch.arange(max_length, dtype=torch.float32), inv)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return (emb.cos() * scale).to(dtype), (emb.sin() * scale).to(dtype)
