@@ -1,0 +1,182 @@
+/* libumbrella_hip.so -- C ABI of the MI355X (gfx950) speculative-decoding hot path.
+ *
+ * Drop-in boundary for Infini-AI-Lab/UMbreLLa's draft-expand / verify step.  The
+ * reference (100 % Python) reaches native code only through seven third-party
+ * symbols + torch; each entry point below names the reference call site(s) it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions: extern "C"; plain pointers and sizes (no torch types); every
+ * function returns 0 on success or a negative errno-style code (-22 bad
+ * argument, -5 HIP launch error); nothing throws; the caller owns every buffer;
+ * the library allocates nothing; every call is asynchronous on `stream` and
+ * safe to capture into a hipGraph (all run-time state -- prefix length,
+ * positions, slots, accept results -- is read from device memory).
+ *
+ * dtype: 0 = fp16, 1 = bf16 (activations, dense weights, KV cache).
+ */
+#ifndef UMBRELLA_HIP_H
+#define UMBRELLA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* umb_stream_t;   /* == hipStream_t */
+
+/* ------------------------------------------------------------------ weights (load time) */
+/* dense W[N][K] row-major (HF layout; umbrella/models/llama_layer.py:25-40) -> MFMA tile order.
+ * out: N*K 16-bit elements. */
+int umb_repack_dense(void* out, const void* w, int N, int K, int dtype, umb_stream_t stream);
+/* AutoAWQ GEMM tensors (umbrella/quantization/awq_utils.py:20-27: qweight [K][N/8] i32,
+ * qzeros [K/128][N/8] i32, scales [K/128][N] fp16) -> int4 tile order.
+ * outw: N*K/2 bytes, meta: (N/16)*(K/128)*48 bytes (16 fp16 scales + 16 u8 zeros per tile). */
+int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
+                   int N, int K, int group, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ linear layers */
+/* split plan for a [N][K] linear: depends on (N, K, format) only, never on T. */
+void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out);
+/* out[S][T][N] (fp32 split-K partials) = x[T][K] (row stride ldx) . W^T
+ * replaces F.linear (umbrella/models/llama.py:89-91,103,107-111,133) and
+ * AwqLinear.apply -> awq_ext.gemm_forward_cuda / dequantize_weights_cuda
+ * (umbrella/quantization/awq_utils.py:63-86).  round_out: round results to `dtype`
+ * (what F.linear(...).float() yields for the lm_head, llama.py:133). */
+int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
+             int awq, int S, int R, int round_out, int dtype, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ fused epilogues */
+/* flashinfer.rmsnorm (umbrella/models/model_utils.py:54-64) */
+int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype, umb_stream_t stream);
+/* h = residual + sum_s partial ; xn = rmsnorm(h)*w   (llama.py:104-106,112-113 + next layer's :87) */
+int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
+                             void* xn_out, const void* w, float eps, int dtype, umb_stream_t stream);
+/* act = silu(gate) * up  (llama.py:107-110); partial rows are [gate | up] */
+int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
+/* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
+ * + KV_Cache.update_kv_cache (umbrella/attn/cache.py:53-65) at slots slot[t].
+ * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax] (layer base pointers). */
+int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
+                        const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
+                        void* vt_cache, int dtype, umb_stream_t stream);
+/* F.embedding (llama.py:124) + per-forward position/slot/prefix resolution.
+ * explicit mode: tok/pos/slot/prefix given.  tree mode (tokens_all != NULL):
+ * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i. */
+int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
+                   const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
+                   int* pos_out, int* slot_out, int* prefix_out, int dtype, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ attention */
+/* flashinfer.single_prefill_with_kv_cache(custom_mask=...) (umbrella/attn/cache.py:77-85) and
+ * StaticKV_Cache.compute_attention (cache.py:169-192).  Keys [0,*prefix_len) are visible to every
+ * row; key *prefix_len + b is visible to row t iff bit b of mask_bits[t*mask_words ...] (NULL: b <= t).
+ * po: [max_splits][T][Hq][D] fp32, pml: [max_splits][T][Hq][2] fp32 scratch; chunk*max_splits >= Lmax. */
+int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
+                  const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T, int Hq,
+                  int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, int dtype, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ tree bookkeeping */
+/* target_logits.argmax(-1) (static_speculation_engine.py:307) */
+int umb_argmax_rows(int* out, const float* logits, int rows, int V, umb_stream_t stream);
+/* topk per row (speculation_utils.py:57-61; dynamic_speculation_engine.py:236); optional Sequoia child
+ * placement tokens_all[*n_ptr + child_start[row] + r] = idx[r], r < child_cnt[row] (static:115-123,279-281) */
+int umb_topk_rows(int* out_idx, float* out_val, const float* logits, int rows, int V, int k, int* tokens_all,
+                  const int* n_ptr, const int* child_start, const int* child_cnt, umb_stream_t stream);
+/* SpecExec beam expansion of one level (dynamic_speculation_engine.py:236-248) */
+int umb_beam_expand(const int* top_idx, const float* top_val, int w, int B, int W, int lvl_off, float* tree_score,
+                    int* parents, int* tokens_all, const int* n_ptr, void* mask_bits, int mask_words,
+                    umb_stream_t stream);
+/* accept scan + token / num_nodes update + EOS search (static:313-341, dynamic:283-316).
+ * out5 = {kept, bonus token, eos hit, new num_nodes, raw accept length}; path[i] = i-th accepted tree index */
+int umb_accept_scan(const int* sampled, const int* parents, int* tokens_all, int* n_ptr, int T, const int* eos,
+                    int n_eos, int* out5, int* path, umb_stream_t stream);
+/* KV_Cache.gather_kv_incremental (umbrella/attn/cache.py:41-49) without the tail memset */
+int umb_kv_compact(void* k_cache, void* vt_cache, const int* res, const int* path, int L, int Hkv, int D, int Lmax,
+                   int max_path, int dtype, umb_stream_t stream);
+int umb_set_int(int* p, int v, umb_stream_t stream);
+/* target_logits[-1:, eos] = -inf (dynamic_speculation_engine.py:130,163) */
+int umb_mask_eos(float* logits_row, const int* eos, int n_eos, umb_stream_t stream);
+int umb_write_token(int* tokens_all, const int* n_ptr, const int* src, umb_stream_t stream);
+/* measurement knob: tokens_all[*n_ptr + off + i] = tbl[off + i] where tbl >= 0 (controllable-acceptance draft) */
+int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ whole-model forward */
+typedef struct UmbLinear {
+  const void* w;        /* packed tiles */
+  const void* meta;     /* AWQ scale/zero tiles or NULL */
+  int32_t N, K, awq, R, S;
+  int32_t pad_;
+} UmbLinear;
+
+typedef struct UmbLayer {
+  UmbLinear qkv, o, gu, down;       /* fused [q|k|v], o_proj, fused [gate|up], down_proj */
+  const void* norm1;                /* input_layernorm weight [H] */
+  const void* norm2;                /* post_attention_layernorm weight [H] */
+} UmbLayer;
+
+typedef struct UmbModel {
+  int32_t dtype, L, H, I, Hq, Hkv, D, V, Lmax, pad_;
+  float eps, attn_scale;
+  const void* embed;                /* [V][H] row-major */
+  UmbLinear lm_head;
+  const void* final_norm;
+  const void* rope_cos;             /* [Lmax][D] model dtype (umbrella/models/llama.py:48-60) */
+  const void* rope_sin;
+  void* k_cache;                    /* [L][Hkv][Lmax][D] */
+  void* vt_cache;                   /* [L][Hkv][D][Lmax] */
+  const UmbLayer* layers;           /* host array, L entries */
+} UmbModel;
+
+typedef struct UmbWorkspace {
+  void* h;  void* xn;  void* q;  void* attn;  void* act;   /* [Tmax][H|H|Hq*D|Hq*D|I] 16-bit */
+  float* partial;                   /* split-K partials, >= max S*Tmax*N floats */
+  float* attn_po;  float* attn_ml;
+  int32_t* pos;  int32_t* slot;  int32_t* prefix;
+  float* logits;                    /* [Tmax][V] */
+  int32_t Tmax, attn_chunk, attn_splits, pad_;
+} UmbWorkspace;
+
+typedef struct UmbStep {
+  int32_t T;
+  int32_t tree_off;                 /* tree mode: offset of the first query row inside the tree */
+  const int32_t* tokens;            /* explicit mode */
+  const int32_t* positions;
+  const int32_t* slots;
+  const int32_t* prefix_len;
+  const int32_t* tokens_all;        /* tree mode: engine token buffer (NULL -> explicit mode) */
+  const int32_t* n_ptr;             /* device scalar: num_nodes */
+  const int32_t* depth;             /* tree depth table */
+  const void* mask_bits;            /* rows for the T queries (row stride mask_words u64), NULL = causal */
+  int32_t mask_words, n_mask_keys;
+  int32_t head_from;                /* lm_head over rows [head_from, T) -> logits rows [0, T-head_from); >= T: skip */
+  int32_t layer_begin, layer_end;   /* pipeline stage [begin, end); 0, L for the whole model */
+  int32_t skip_embed;               /* stage > 0: ws.h already holds the incoming activations;
+                                       positions/slots/prefix are still resolved */
+} UmbStep;
+
+/* Llama*.inference (umbrella/models/llama.py:117-134, 305-322): embedding -> layers -> norm -> lm_head.
+ * fp32 logits land in ws->logits. */
+int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, umb_stream_t stream);
+
+/* LlamaOffload / LlamaAwqOffload.inference (llama.py:196-219): layers whose weights live in pinned
+ * host slabs are streamed into two device slabs on copy_stream, event-ordered against compute.
+ * host_slabs[l] == NULL -> layer l is device resident (its UmbLayer pointers are used as is);
+ * otherwise layers[l] pointers are offsets relative to the slab base. */
+typedef struct UmbOffload {
+  void* const* host_slabs;          /* L entries */
+  size_t slab_bytes;
+  void* dev_slab[2];
+  umb_stream_t copy_stream;
+  void* ev_copied[2];               /* hipEvent_t */
+  void* ev_free[2];
+} UmbOffload;
+int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbOffload* off,
+                              umb_stream_t stream);
+
+const char* umb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

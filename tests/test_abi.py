@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/umbrella_hip.h declares; host-side formats round-trip.  No compute calls."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from umbrella_amd import _lib
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from umbrella_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "umbrella_hip.h")).read()
+    declared = set(re.findall(r"\b(umb_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/umbrella_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.umb_version().startswith(b"umbrella_hip")
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors must have the C struct sizes (LP64)."""
+    import ctypes as C
+    from umbrella_amd import _lib
+    assert C.sizeof(_lib.UmbLinear) == 40
+    assert C.sizeof(_lib.UmbLayer) == 4 * 40 + 16
+    assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 40 + 6 * 8
+    assert C.sizeof(_lib.UmbWorkspace) == 12 * 8 + 16
+    assert C.sizeof(_lib.UmbStep) == 8 + 8 * 8 + 6 * 4
+    assert C.sizeof(_lib.UmbOffload) == 8 + 8 + 16 + 8 + 16 + 16
+
+
+def test_gemm_plan_is_token_count_free(lib):
+    import ctypes as C
+    for (N, K, awq) in ((3072, 2048, 0), (128256, 2048, 0), (10240, 8192, 1), (57344, 8192, 1), (8192, 28672, 1)):
+        R, S = C.c_int(), C.c_int()
+        lib.umb_gemm_plan(N, K, awq, 0, C.byref(R), C.byref(S))
+        assert (N // 16) % R.value == 0 and 1 <= S.value <= 16 and (K // 128) >= S.value
+        lib.umb_gemm_plan(N, K, awq, 1, C.byref(R), C.byref(S))
+        assert S.value == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from umbrella_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libumbrella_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_mask_bit_packing():
+    from umbrella_amd.models.llama import pack_mask_bits
+    rs = np.random.RandomState(0)
+    for T, Cn in ((13, 13), (31, 31), (70, 130), (5, 64), (3, 65)):
+        m = torch.from_numpy(rs.rand(T, Cn) > 0.5)
+        bits = pack_mask_bits(m)
+        assert bits.shape == (T, (Cn + 63) // 64)
+        back = torch.zeros(T, Cn, dtype=torch.bool)
+        for t in range(T):
+            for c in range(Cn):
+                back[t, c] = (int(bits[t, c // 64]) >> (c % 64)) & 1
+        assert torch.equal(back, m)
+
+
+def test_sequoia_generator_and_expected_accept():
+    import json
+    from umbrella_amd.sequoia_utils import expected_accept_length, generate_sequoia_tree
+    with open(os.path.join(ROOT, "tests", "golden", "growmaps.json")) as f:
+        gm = json.load(f)
+    assert generate_sequoia_tree(3, 4) == gm["3x4"]                 # == the reference's shipped 3x4 tree
+    assert generate_sequoia_tree(5, 6, gm["5x6_acc"]) == gm["5x6"]
+    with open(os.path.join(ROOT, "umbrella_amd", "trees", "sequoia_tree-3x4.json")) as f:
+        assert json.load(f) == gm["3x4"]
+    e = expected_accept_length(gm["3x4"], [0.65, 0.2, 0.1, 0.05])
+    assert 3.0 < e < 3.6
+
+
+def test_config_table_and_rope():
+    from umbrella_amd.models.config import KNOWN, rope_tables
+    c = KNOWN["hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4"]
+    assert (c.num_hidden_layers, c.hidden_size, c.intermediate_size, c.num_attention_heads, c.head_dim) == (80, 8192, 28672, 64, 128)
+    d = KNOWN["meta-llama/Llama-3.2-1B-Instruct"]
+    cos, sin = rope_tables(d, 64, torch.bfloat16)
+    assert cos.shape == (64, 64) and cos.dtype == torch.bfloat16 and float(cos[0, 0]) == 1.0 and float(sin[0, 0]) == 0.0

@@ -1,0 +1,221 @@
+"""Model- and engine-level parity on the GPU: HIP runtime vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_golden, oracle_model                      # noqa: E402
+
+G = load_golden()
+PROMPT = G["cases"]["static_3x4_selfdraft"]["prompt"]              # 40 tokens
+PROMPT_S = G["cases"]["static_3x4"]["prompt"]                      # 24 tokens
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("awq", [False, True])
+def test_model_logits_vs_oracle(dev, dtype, awq):
+    """Llama.inference through the reference face vs OracleLlama (fp32 arithmetic on the same weights)."""
+    from hip_helpers import hip_model
+    m, sd = hip_model(G["target_cfg"], G["seeds"]["target"], 128, dtype, dev, awq=awq)
+    if not awq:                       # weights are rounded to the model dtype on the GPU: do the same for the oracle
+        sd = {k: v.to(dtype).float() for k, v in sd.items()}
+    else:
+        sd = {k: (v.to(dtype).float() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    o = oracle_model(G["target_cfg"], G["seeds"]["target"], 128, torch.float32, state=sd)
+    ids = torch.tensor([PROMPT_S])
+    T = ids.shape[1]
+    mask = torch.tril(torch.ones(T, 128, dtype=torch.bool))
+    ref = o.inference(ids, torch.arange(T)[None], mask, torch.arange(T))[0]
+    got = m.inference(ids.to(dev), torch.arange(T)[None], mask, torch.arange(T))[0].cpu()
+    tol = 0.25 if dtype == torch.bfloat16 else 0.05
+    assert (got - ref).abs().max() < tol, float((got - ref).abs().max())
+    # tree-shaped second call on top of the cached prefix: 5 nodes, chain + siblings
+    tm = torch.tensor([[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [1, 0, 1, 0, 0], [1, 1, 0, 1, 0], [1, 0, 1, 0, 1]]) == 1
+    mask2 = torch.zeros(5, 128, dtype=torch.bool)
+    mask2[:, :T] = True
+    mask2[:, T:T + 5] = tm
+    ids2 = torch.tensor([[7, 8, 9, 10, 11]])
+    pos2 = torch.tensor([[T, T + 1, T + 1, T + 2, T + 2]])
+    sl2 = torch.arange(T, T + 5)
+    ref2 = o.inference(ids2, pos2, mask2, sl2)[0]
+    got2 = m.inference(ids2.to(dev), pos2, mask2, sl2)[0].cpu()
+    assert (got2 - ref2).abs().max() < tol, float((got2 - ref2).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_static_selfdraft_generate(dev, dtype):
+    from hip_helpers import check_greedy, static_engine
+    eng, sd = static_engine(G, dev, dtype, self_draft=True)
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=48)
+    toks = out["generated_tokens"]
+    assert len(toks) >= 48
+    check_greedy(G, sd, PROMPT, toks, dtype)
+    assert out["avg_accept_tokens"] > 2.5, out["avg_accept_tokens"]
+    # stateless across calls (generate() ends with reset()): same request, same answer
+    out2 = eng.generate(input_ids=PROMPT, max_new_tokens=48)
+    assert out2["generated_tokens"] == toks
+
+
+def test_static_graph_equals_eager_and_ar(dev):
+    """hipGraph replay == eager launches, and greedy speculative == greedy autoregressive
+    (the target alone, T = 1 steps) token for token -- the GEMMs are batch-invariant."""
+    from hip_helpers import static_engine
+    dtype = torch.bfloat16
+    e1, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=True)
+    e2, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=False)
+    t1 = e1.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"]
+    t2 = e2.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"]
+    assert t1 == t2
+    # autoregressive decode with the target model only
+    m = e2.target_model
+    m.clear()
+    ids = torch.tensor(PROMPT, dtype=torch.int32, device=dev)
+    row = m.prefill_tokens(ids, 0)
+    ar = [int(row.argmax())]
+    for i in range(39):
+        row = m.prefill_tokens(torch.tensor([ar[-1]], dtype=torch.int32, device=dev), len(PROMPT) + i)
+        ar.append(int(row.argmax()))
+    n = min(len(ar), len(t1))
+    same = sum(a == b for a, b in zip(ar[:n], t1[:n]))
+    assert ar[:n] == t1[:n], f"spec != AR ({same}/{n} equal)"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_static_small_draft_and_5x6(dev, dtype):
+    from hip_helpers import check_greedy, static_engine
+    eng, sd = static_engine(G, dev, dtype, self_draft=False)
+    out = eng.generate(input_ids=PROMPT_S, max_new_tokens=30)
+    check_greedy(G, sd, PROMPT_S, out["generated_tokens"], dtype)
+    assert 1.0 <= out["avg_accept_tokens"] < 2.0
+    eng, sd = static_engine(G, dev, dtype, self_draft=True, gm="5x6")
+    out = eng.generate(input_ids=PROMPT_S, max_new_tokens=48)
+    check_greedy(G, sd, PROMPT_S, out["generated_tokens"], dtype)
+    assert out["avg_accept_tokens"] > 3.0
+
+
+def test_static_awq_target(dev):
+    from hip_helpers import check_greedy, static_engine
+    dtype = torch.float16
+    eng, sd = static_engine(G, dev, dtype, self_draft=True, awq=True)
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=32)
+    check_greedy(G, sd, PROMPT, out["generated_tokens"], dtype, tol=0.12)
+    assert out["avg_accept_tokens"] > 2.5
+
+
+def test_static_two_turns_eos_and_overflow(dev):
+    from hip_helpers import check_greedy, static_engine
+    dtype = torch.bfloat16
+    case = G["cases"]["static_3x4"]
+    eng, sd = static_engine(G, dev, dtype, self_draft=True)
+    assert eng._prefill(torch.tensor([case["prompt"]])) is True
+    start = eng.num_nodes
+    go = True
+    while go and eng.num_nodes - start < 20:
+        go = eng.step()
+    turn1 = eng.tokens[start:eng.num_nodes + 1].tolist()
+    check_greedy(G, sd, case["prompt"], turn1, dtype)
+    assert eng._append(torch.tensor([case["append"]])) is True
+    start2 = eng.num_nodes
+    while eng.num_nodes - start2 < 12:
+        eng.step()
+    ctx = case["prompt"] + turn1 + case["append"]
+    assert eng.tokens[:start2].tolist() == ctx
+    check_greedy(G, sd, ctx, eng.tokens[start2:eng.num_nodes + 1].tolist(), dtype)
+    # EOS inside the accepted path: stop there, EOS itself is not kept in the KV
+    eos_tok = turn1[6]
+    eng2, _ = static_engine(G, dev, dtype, self_draft=True, eos=(eos_tok,))
+    out = eng2.generate(input_ids=case["prompt"], max_new_tokens=40)
+    toks = out["generated_tokens"]
+    assert eos_tok in toks and toks.index(eos_tok) <= 6 and len(toks) < 20
+    # overflow -> False / empty result, never raises (static:146-147,401-406)
+    eng3, _ = static_engine(G, dev, dtype, self_draft=True, max_length=64)
+    assert eng3._prefill(torch.tensor([list(range(6, 6 + 40))])) is False
+    out = eng3.generate(input_ids=list(range(6, 6 + 40)), max_new_tokens=8)
+    assert out["generated_tokens"] == [] and out["avg_accept_tokens"] == 0
+    assert eng3.generate(input_ids=[], max_new_tokens=8)["generated_tokens"] == []
+
+
+@pytest.mark.parametrize("self_draft", [True, False])
+def test_dynamic_generate(dev, self_draft):
+    from hip_helpers import check_greedy, dynamic_engine
+    dtype = torch.bfloat16
+    eng, sd = dynamic_engine(G, dev, dtype, self_draft=self_draft, width=8, num_beams=8, depth=4)
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=40)
+    toks = out["generated_tokens"]
+    check_greedy(G, sd, PROMPT, toks, dtype, mask_first_eos=eng.eos_tokens)
+    if self_draft:
+        assert out["avg_accept_tokens"] > 2.5, out["avg_accept_tokens"]
+
+
+def test_dynamic_wide_tree_and_offload(dev):
+    """T = 16*6+1 = 97 tokens per verify (token chunks > 64 in the GEMM) and the layer-streaming target."""
+    from hip_helpers import check_greedy, dynamic_engine
+    dtype = torch.bfloat16
+    eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=12, depth=6, offload=False)
+    ref = eng.generate(input_ids=PROMPT, max_new_tokens=40)
+    check_greedy(G, sd, PROMPT, ref["generated_tokens"], dtype, mask_first_eos=eng.eos_tokens)
+    for ncache in (0, 2):
+        eng2, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=12, depth=6, offload=True,
+                                 num_cache_layers=ncache)
+        assert eng2.target_model._off is not None
+        out = eng2.generate(input_ids=PROMPT, max_new_tokens=40)
+        assert out["generated_tokens"] == ref["generated_tokens"]
+
+
+def test_stochastic_sampling_support(dev):
+    """temperature > 0: sampled tokens stay inside the top-k / top-p support of the oracle's filtered
+    target distribution (distributional parity only -- RNG streams differ)."""
+    from hip_helpers import dynamic_engine
+    dtype = torch.bfloat16
+    eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=4, num_beams=6, depth=3, temperature=0.6,
+                             topp=0.9, topk=8)
+    assert eng._prefill(torch.tensor([PROMPT]))
+    start = eng.num_nodes
+    for _ in range(6):
+        eng.step()
+    toks = eng.tokens[start + 1:eng.num_nodes + 1].tolist()
+    seq = PROMPT + eng.tokens[start:eng.num_nodes + 1].tolist()
+    o = oracle_model(G["target_cfg"], G["seeds"]["target"], len(seq) + 1, torch.float32, state=sd)
+    n = len(seq)
+    logits = o.inference(torch.tensor([seq]), torch.arange(n)[None], torch.tril(torch.ones(n, n + 1, dtype=torch.bool)),
+                         torch.arange(n))[0]
+    for i, tok in enumerate(toks):
+        row = logits[len(PROMPT) + i]
+        rank = int((row > row[tok]).sum())
+        assert rank < 8 + 2, (i, tok, rank)          # inside top-k (+2 slack for 16-bit near-ties at the boundary)
+
+
+def test_reference_face_and_awq_linear(dev):
+    """AutoEngine / AutoModelLM / AwqLinear keep the reference's contracts."""
+    from umbrella_amd.models import AutoModelLM
+    from umbrella_amd.quantization.awq_utils import AwqLinear
+    from umbrella_amd.speculation.auto_engine import AutoEngine
+    with pytest.raises(ValueError):
+        AutoEngine.from_config("cuda:0", engine="nope", model="a", draft_model="b")
+    with pytest.raises(AssertionError):
+        AutoEngine.from_config("cuda:0", engine="static", model="a")
+    with pytest.raises(ValueError):
+        AutoModelLM.from_pretrained("not/a-model")
+    from oracle import ops as O
+    from umbrella_amd.models.awq_format import pack_rows
+    rs = np.random.RandomState(0)
+    K, N = 256, 512
+    q = rs.randint(0, 16, size=(K, N)).astype(np.uint8); z = rs.randint(0, 16, size=(K // 128, N)).astype(np.uint8)
+    s = (rs.rand(K // 128, N) * 0.02 + 0.002).astype(np.float16)
+
+    class Mod:
+        in_features, out_features, w_bit, group_size, bias = K, N, 4, 128, None
+        qweight, qzeros, scales = torch.from_numpy(pack_rows(q)), torch.from_numpy(pack_rows(z)), torch.from_numpy(s)
+    lin = AwqLinear(); lin.init_parameters(Mod()); lin.to("cuda:0")
+    x = torch.from_numpy(rs.randn(1, 5, K).astype(np.float32)).half()
+    out = lin.apply(x.to(dev))
+    assert out.shape == (1, 5, N) and out.dtype == torch.float16
+    ref = O.awq_linear(x[0].float(), Mod.qweight, Mod.qzeros, Mod.scales, 128)
+    assert (out[0].cpu().float() - ref).abs().max() < 0.02 * ref.abs().max()

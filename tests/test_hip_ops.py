@@ -1,0 +1,293 @@
+"""Kernel-level parity (GPU): every HIP op through the C ABI vs the CPU oracle / fp32 torch."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O                                     # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from umbrella_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-9))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(512, 256), (3072, 2048), (4096 + 16, 1024), (128256, 256)])
+@pytest.mark.parametrize("T", [1, 5, 13, 16, 17, 33, 64, 70])
+def test_gemm_dense(dev, dtype, N, K, T):
+    from umbrella_amd.models.llama import PackedLinear
+    g = torch.Generator(device="cpu").manual_seed(N + K + T)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    x = torch.randn(T, K, generator=g).to(dtype)
+    lin = PackedLinear.from_dense(w.to(dev))
+    out = lin.apply(x.to(dev)).cpu()
+    ref = x.float() @ w.float().t()
+    assert _rel(out, ref) < 2e-3, (lin.R, lin.S, _rel(out, ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(512, 256), (1024, 2048), (28672 // 4, 1024)])
+@pytest.mark.parametrize("T", [1, 13, 16, 31, 40, 64, 65])
+def test_gemm_awq(dev, dtype, N, K, T):
+    from umbrella_amd.models.awq_format import pack_rows
+    from umbrella_amd.models.llama import PackedLinear
+    rs = np.random.RandomState(N + K + T)
+    q = rs.randint(0, 16, size=(K, N)).astype(np.uint8)
+    z = rs.randint(0, 16, size=(K // 128, N)).astype(np.uint8)
+    s = (rs.rand(K // 128, N) * 0.02 + 0.002).astype(np.float16)
+    qw, qz, sc = torch.from_numpy(pack_rows(q)), torch.from_numpy(pack_rows(z)), torch.from_numpy(s)
+    x = torch.from_numpy(rs.randn(T, K).astype(np.float32)).to(dtype)
+    lin = PackedLinear.from_awq(qw.to(dev), qz.to(dev), sc.to(dev))
+    out = lin.apply(x.to(dev)).cpu()
+    W = (q.astype(np.float32) - np.repeat(z, 128, 0)) * np.repeat(s.astype(np.float32), 128, 0)   # exact (q-z)*s
+    ref = x.float() @ torch.from_numpy(W)
+    assert _rel(out, ref) < 2e-3, (lin.R, lin.S, _rel(out, ref))
+    # and the oracle's AwqLinear restatement (fp16-rounded W) within fp16 weight rounding
+    ref2 = O.awq_linear(x.float(), qw, qz, sc, 128)
+    assert _rel(out, ref2) < 5e-3
+
+
+def test_gemm_batch_invariance(dev):
+    """A token's result must not depend on how many other tokens share the launch."""
+    from umbrella_amd.models.llama import PackedLinear
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(3072, 2048, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    x = torch.randn(40, 2048, generator=g).to(torch.bfloat16).to(dev)
+    lin = PackedLinear.from_dense(w)
+    full = lin.apply(x)
+    for T in (1, 13, 17, 33):
+        assert torch.equal(lin.apply(x[:T].contiguous()), full[:T])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rmsnorm(dev, dtype):
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(13, 2048, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(2048, generator=g)).to(dtype)
+    out = torch.empty_like(x, device=dev)
+    _lib.call("umb_rmsnorm", out, x.to(dev), w.to(dev), 1e-5, 13, 2048, _lib.dtype_code(dtype))
+    ref = O.rmsnorm(x, w, 1e-5)
+    assert (out.cpu().float() - ref.float()).abs().max() <= 2 * torch.finfo(dtype).eps * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_reduce_residual_norm_and_silu(dev, dtype):
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    S, T, N = 3, 13, 512
+    part = torch.randn(S, T, N, generator=g)
+    res = torch.randn(T, N, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype)
+    h = torch.empty(T, N, dtype=dtype, device=dev)
+    xn = torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_residual_norm", part.to(dev), S, T, N, res.to(dev), h, xn, w.to(dev), 1e-5, _lib.dtype_code(dtype))
+    href = (part.sum(0).to(dtype) + res)
+    assert (h.cpu().float() - href.float()).abs().max() <= 2 * torch.finfo(dtype).eps * href.float().abs().max()
+    xref = O.rmsnorm(h.cpu(), w, 1e-5)
+    assert (xn.cpu().float() - xref.float()).abs().max() <= 2 * torch.finfo(dtype).eps * xref.float().abs().max()
+    I = 256
+    act = torch.empty(T, I, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_silu_mul", part.to(dev), S, T, I, act, _lib.dtype_code(dtype))
+    gate, up = part.sum(0)[:, :I].to(dtype), part.sum(0)[:, I:].to(dtype)
+    aref = torch.nn.functional.silu(gate) * up
+    assert (act.cpu().float() - aref.float()).abs().max() <= 4 * torch.finfo(dtype).eps * aref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_qkv_rope_kv_append(dev, dtype):
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    T, Hq, Hkv, D, Lmax = 7, 4, 2, 64, 64
+    N = (Hq + 2 * Hkv) * D
+    part = torch.randn(2, T, N, generator=g)
+    pos = torch.tensor([9, 10, 10, 11, 11, 11, 12], dtype=torch.int32)
+    slot = torch.arange(20, 27, dtype=torch.int32)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, D, 2).float() / D))
+    cos, sin = O.rope_cache(inv, 1.0, Lmax, dtype)
+    q = torch.zeros(T, Hq, D, dtype=dtype, device=dev)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev)
+    vt = torch.zeros(Hkv, D, Lmax, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_qkv_rope", part.to(dev), 2, T, Hq, Hkv, D, Lmax, pos.to(dev), slot.to(dev), cos.to(dev),
+              sin.to(dev), q, kc, vt, _lib.dtype_code(dtype))
+    full = part.sum(0).to(dtype)
+    qr, kr, vr = full[:, :Hq * D].view(T, Hq, D), full[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D), full[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    qe, ke = O.apply_rope(qr, kr, cos, sin, pos.long())
+    eps = torch.finfo(dtype).eps
+    assert (q.cpu().float() - qe.float()).abs().max() <= 2 * eps * qe.float().abs().max()
+    kgot = kc.cpu()[:, 20:27].permute(1, 0, 2)
+    assert (kgot.float() - ke.float()).abs().max() <= 2 * eps * ke.float().abs().max()
+    vgot = vt.cpu()[:, :, 20:27].permute(2, 0, 1)
+    assert torch.equal(vgot, vr)
+    assert kc.cpu()[:, :20].abs().max() == 0 and vt.cpu()[:, :, 27:].abs().max() == 0
+
+
+def _tree_mask(T, rs):
+    par = [0] + [int(rs.randint(0, i)) for i in range(1, T)]
+    m = torch.zeros(T, T, dtype=torch.bool)
+    for i in range(T):
+        j = i
+        while True:
+            m[i, j] = True
+            if j == 0:
+                break
+            j = par[j]
+    return m
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(4, 2, 64), (8, 1, 128), (32, 8, 64), (4, 4, 32)])
+@pytest.mark.parametrize("T,prefix", [(1, 0), (1, 300), (13, 5), (13, 777), (31, 64), (70, 129)])
+def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix):
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import pack_mask_bits
+    rs = np.random.RandomState(T * 1000 + prefix + D)
+    g = torch.Generator().manual_seed(T + prefix)
+    Lmax, chunk = 1024, 256
+    splits = Lmax // chunk
+    S = prefix + T
+    q = torch.randn(T, Hq, D, generator=g).to(dtype)
+    k = torch.randn(S, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(S, Hkv, D, generator=g).to(dtype)
+    tm = _tree_mask(T, rs)
+    mask = torch.cat([torch.ones(T, prefix, dtype=torch.bool), tm], dim=1)
+    ref = O.masked_attention(q.float(), k.float(), v.float(), mask)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype)
+    vt = torch.zeros(Hkv, D, Lmax, dtype=dtype)
+    kc[:, :S] = k.permute(1, 0, 2)
+    vt[:, :, :S] = v.permute(1, 2, 0)
+    # stale garbage after the valid region must be ignored
+    kc[:, S:S + 40] = 7.0
+    vt[:, :, S:S + 40] = -9.0
+    bits = pack_mask_bits(tm).to(dev)
+    out = torch.empty(T, Hq, D, dtype=dtype, device=dev)
+    po = torch.empty(splits * T * Hq * D, dtype=torch.float32, device=dev)
+    pml = torch.empty(splits * T * Hq * 2, dtype=torch.float32, device=dev)
+    pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
+    _lib.call("umb_tree_attn", out, q.to(dev), kc.to(dev), vt.to(dev), po, pml, pre, bits, bits.shape[1], T, T, Hq, Hkv,
+              D, Lmax, chunk, splits, 1.0 / math.sqrt(D), _lib.dtype_code(dtype))
+    err = (out.cpu().float() - ref).abs().max()
+    assert err < (0.03 if dtype == torch.bfloat16 else 0.004), float(err)
+    # causal mode (mask_bits = NULL): row t sees prefix + new keys 0..t
+    _lib.call("umb_tree_attn", out, q.to(dev), kc.to(dev), vt.to(dev), po, pml, pre, None, 0, T, T, Hq, Hkv, D, Lmax,
+              chunk, splits, 1.0 / math.sqrt(D), _lib.dtype_code(dtype))
+    cm = torch.cat([torch.ones(T, prefix, dtype=torch.bool), torch.tril(torch.ones(T, T, dtype=torch.bool))], dim=1)
+    ref = O.masked_attention(q.float(), k.float(), v.float(), cm)
+    err = (out.cpu().float() - ref).abs().max()
+    assert err < (0.03 if dtype == torch.bfloat16 else 0.004), float(err)
+
+
+def test_argmax_and_topk(dev):
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(4)
+    for V in (512, 128256):
+        logits = torch.randn(7, V, generator=g)
+        logits[2, 100] = logits[2, 50] = 9.0                    # tie -> lower index
+        logits = logits.bfloat16().float()                       # bf16-rounded logits produce many exact ties
+        d = logits.to(dev)
+        am = torch.empty(7, dtype=torch.int32, device=dev)
+        _lib.call("umb_argmax_rows", am, d, 7, V)
+        assert am.cpu().tolist() == logits.argmax(-1).tolist()
+        assert am.cpu()[2] == 50
+        for k in (1, 3, 8, 24, 32):
+            idx = torch.empty(7, k, dtype=torch.int32, device=dev)
+            val = torch.empty(7, k, dtype=torch.float32, device=dev)
+            _lib.call("umb_topk_rows", idx, val, d, 7, V, k, None, None, None, None)
+            tv, _ = logits.topk(k, dim=-1)
+            assert torch.equal(val.cpu(), tv)
+            assert torch.equal(torch.gather(logits, 1, idx.cpu().long()), tv)
+            # ties in index order, no duplicates
+            for r in range(7):
+                row = idx.cpu()[r].tolist()
+                assert len(set(row)) == k
+                for a in range(k - 1):
+                    if tv[r, a] == tv[r, a + 1]:
+                        assert row[a] < row[a + 1]
+    # pathological: all equal -> the k lowest indices
+    d = torch.zeros(2, 5000, device=dev)
+    idx = torch.empty(2, 8, dtype=torch.int32, device=dev)
+    _lib.call("umb_topk_rows", idx, None, d, 2, 5000, 8, None, None, None, None)
+    assert idx.cpu().tolist() == [list(range(8))] * 2
+
+
+def test_topk_places_sequoia_children(dev):
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(3, 512, generator=g)
+    tokens = torch.zeros(64, dtype=torch.int32, device=dev)
+    n = torch.tensor([10], dtype=torch.int32, device=dev)
+    cs = torch.tensor([4, 6, 7], dtype=torch.int32, device=dev)
+    cc = torch.tensor([2, 1, 0], dtype=torch.int32, device=dev)
+    _lib.call("umb_topk_rows", None, None, logits.to(dev), 3, 512, 2, tokens, n, cs, cc)
+    exp = O.topk_flatten_gather(logits, 2, torch.tensor([0, 1, 2]))
+    assert tokens.cpu()[14:17].tolist() == exp.tolist()
+    assert tokens.cpu()[17:].abs().sum() == 0 and tokens.cpu()[:14].abs().sum() == 0
+
+
+def test_accept_scan_matches_oracle(dev):
+    from oracle import sequoia
+    from umbrella_amd import _lib
+    rs = np.random.RandomState(7)
+    for name, gm in (("3x4", sequoia.generate(3, 4)), ("5x6", sequoia.generate(5, 6, [0.5, 0.2, 0.12, 0.08, 0.05, 0.03]))):
+        T = gm["size"]
+        mask = torch.tensor(gm["mask"]) == 1
+        want = mask.sum(-1)
+        parents = torch.zeros(T, dtype=torch.int32)
+        for v, s in enumerate(gm["Successors"]):
+            parents[s] = v
+        for trial in range(60):
+            n = int(rs.randint(0, 50))
+            spec = torch.from_numpy(rs.randint(10, 14, size=T)).int()
+            sampled = torch.from_numpy(rs.randint(10, 14, size=T)).int()
+            eos = [13] if trial % 3 == 0 else [999]
+            path, bonus = O.accept_scan(sampled, spec, parents, mask, want)
+            a = len(path)
+            toks = spec[path].tolist() + [bonus]
+            e = O.first_eos(toks, eos)
+            keep = e if e >= 0 else a
+            tokens = torch.zeros(128, dtype=torch.int32)
+            tokens[n:n + T] = spec
+            td, nd = tokens.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+            res = torch.zeros(8, dtype=torch.int32, device=dev)
+            pth = torch.zeros(16, dtype=torch.int32, device=dev)
+            _lib.call("umb_accept_scan", sampled.to(dev), parents.to(dev), td, nd, T, torch.tensor(eos, dtype=torch.int32, device=dev),
+                      1, res, pth)
+            r = res.cpu().tolist()
+            assert r[:5] == [keep, bonus, int(e >= 0), n + keep, a], (name, trial, r, keep, bonus, e, a)
+            assert pth.cpu()[:keep].tolist() == path[:keep].tolist()
+            assert td.cpu()[n:n + a + 1].tolist() == toks
+            assert int(nd.cpu()) == n + keep
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_kv_compaction(dev, D):
+    from umbrella_amd.attn.cache import TreeKVCache
+    L, Hkv, Lmax = 3, 2, 64
+    c = TreeKVCache(L, Hkv, D, Lmax, dev, torch.bfloat16)
+    g = torch.Generator().manual_seed(9)
+    c.k.copy_(torch.randn(c.k.shape, generator=g)); c.vt.copy_(torch.randn(c.vt.shape, generator=g))
+    k0, v0 = c.k.clone(), c.vt.clone()
+    n_old, path = 20, [0, 2, 5, 11]
+    res = torch.tensor([len(path), 0, 0, n_old + len(path), len(path), 0, 0, 0], dtype=torch.int32, device=dev)
+    c.compact(res, torch.tensor(path + [0] * 4, dtype=torch.int32, device=dev), 8)
+    ke, ve = k0.clone(), v0.clone()
+    idx = torch.tensor(path, device=dev) + n_old
+    ke[:, :, n_old:n_old + 4] = k0[:, :, idx]
+    ve[:, :, :, n_old:n_old + 4] = v0[:, :, :, idx]
+    assert torch.equal(c.k, ke) and torch.equal(c.vt, ve)
+    # reference-signature gather gives the same result
+    c2 = TreeKVCache(L, Hkv, D, Lmax, dev, torch.bfloat16)
+    c2.k.copy_(k0); c2.vt.copy_(v0)
+    c2.gather_kv_incremental(idx, n_old)
+    assert torch.equal(c2.k, ke) and torch.equal(c2.vt, ve) and c2.kv_offset == n_old + 4

@@ -1,0 +1,195 @@
+// Tree-masked GQA attention for the draft-expand / verify step (flash-decoding style).
+//
+// Replaces flashinfer.single_prefill_with_kv_cache(custom_mask=...) at
+// umbrella/attn/cache.py:77-85 and the eager masked attention at cache.py:169-192.
+//
+// Instead of a dense [T, n+T] bool mask the kernel takes (prefix_len, bit-packed
+// mask over the key slots after the prefix): key slot c < prefix_len is visible to
+// every row; slot prefix_len + b is visible to row t iff bit b of mask_bits[t] is
+// set (mask_bits == null: causal, b <= t).
+//
+// Layout (chosen for 16-byte MFMA fragment loads, wave64):
+//   q   [T][Hq][D]            K cache [Hkv][Lmax][D]        V cache TRANSPOSED [Hkv][D][Lmax]
+// Per kv head the T*g query rows (g = Hq/Hkv) form 16-row tiles.  The kernel
+// computes S^T = K Q^T so each lane owns ONE query column: softmax statistics
+// are lane-local (+2 cross-lane xor steps), and the exp'd scores are already in
+// B-operand layout for O^T = V^T P^T -- no LDS, no transposes.
+//   grid = (key splits, Hkv, query-tile groups); partial (m, l, O) per split are
+//   merged by attn_combine_kernel.
+#include "common.h"
+
+#define NEG_BIG (-1.0e30f)
+
+template <typename P, int D>
+__global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
+                                                        const u16* __restrict__ vt, float* __restrict__ po,
+                                                        float* __restrict__ pml, const int* __restrict__ prefix_p,
+                                                        const unsigned long long* __restrict__ mask_bits,
+                                                        int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
+                                                        int Lmax, int chunk, int qtiles_per_wave, float scale) {
+  constexpr int DS = D / 32;     // k-steps for Q K^T
+  constexpr int DT = D / 16;     // 16-row d tiles of O^T
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, gq = lane >> 4;
+  const int sp = blockIdx.x, h = blockIdx.y;
+  const int g = Hq / Hkv;
+  const int nrows = T * g;
+  const int prefix = *prefix_p;
+  const int kv_end = prefix + n_mask_keys;
+  const int k_lo = sp * chunk;
+  if (k_lo >= kv_end) return;
+  const int k_hi = min(kv_end, k_lo + chunk);
+  const u16* kbase = kc + (long)h * Lmax * D;
+  const u16* vbase = vt + (long)h * D * Lmax;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  for (int qi = 0; qi < qtiles_per_wave; ++qi) {
+    const int qt = (blockIdx.z * 4 + wv) * qtiles_per_wave + qi;
+    if (qt * 16 >= nrows) break;
+    const int row = qt * 16 + j;                 // this lane's query row (column of S^T)
+    const bool row_ok = row < nrows;
+    const int t = row_ok ? row / g : 0;
+    const int hq = h * g + (row_ok ? row % g : 0);
+    u32x4 bq[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds)
+      bq[ds] = row_ok ? *reinterpret_cast<const u32x4*>(q + ((long)t * Hq + hq) * D + ds * 32 + gq * 8) : zero4;
+
+    float m = NEG_BIG, l = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+      // ---- S^T: two 16-key subtiles; row i of subtile s <-> key k0 + (i>>2)*8 + s*4 + (i&3)
+      f32x4 st[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int key = k0 + (j >> 2) * 8 + s * 4 + (j & 3);
+        const u16* kp = kbase + (long)key * D + gq * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) {
+          const u32x4 ak = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
+          acc = P::mfma(ak, bq[ds], acc);
+        }
+        st[s] = acc;
+      }
+      // lane (j, gq) now holds scores of query row `row` vs keys k0 + gq*8 + s*4 + r
+      float pv[8];
+      float tmax = NEG_BIG;
+      const bool need_mask = (k0 + 32 > prefix);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = k0 + gq * 8 + e;
+        float sc = st[e >> 2][e & 3] * scale;
+        bool vis = row_ok && key < k_hi;
+        if (need_mask && vis && key >= prefix) {
+          const int b = key - prefix;
+          if (mask_bits) vis = (mask_bits[(long)t * mask_words + (b >> 6)] >> (b & 63)) & 1ull;
+          else vis = b <= t;
+        }
+        sc = vis ? sc : -INFINITY;
+        pv[e] = sc;
+        tmax = fmaxf(tmax, sc);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);        // >= NEG_BIG, finite
+      const float alpha = __expf(m - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pv[e] = __expf(pv[e] - m_new); psum += pv[e]; }
+      // probabilities are cast to the model dtype before P V (cache.py:187)
+      u32x4 pb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pb[e] = pack2<P>(pv[2 * e], pv[2 * e + 1]);
+      l = l * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        // A = V^T tile: lane (i = j -> d row, gq) holds keys k0 + gq*8 .. +7 (16 B, 8-key aligned)
+        const u32x4 av = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * Lmax + k0 + gq * 8);
+        o[dt] *= alpha;
+        o[dt] = P::mfma(av, pb, o[dt]);
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (row_ok) {
+      // partial layout follows the output: row index = t*Hq + hq
+      const long prow = ((long)sp * T + t) * Hq + hq;
+      float* op = po + prow * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + gq * 4) = o[dt];
+      if (gq == 0) { pml[prow * 2] = m; pml[prow * 2 + 1] = l; }
+    }
+  }
+}
+
+// merge the per-split partials: one wave per (t, hq) row
+template <typename P, int D>
+__global__ __launch_bounds__(256) void attn_combine_kernel(u16* __restrict__ out, const float* __restrict__ po,
+                                                           const float* __restrict__ pml,
+                                                           const int* __restrict__ prefix_p, int n_mask_keys, int chunk,
+                                                           int rows /* T*Hq */) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int kv_end = *prefix_p + n_mask_keys;
+  const int nsp = (kv_end + chunk - 1) / chunk;
+  float M = NEG_BIG;
+  for (int s = 0; s < nsp; ++s) M = fmaxf(M, pml[((long)s * rows + r) * 2]);
+  float L = 0.f;
+  float acc[D / 64 > 0 ? D / 64 : 1] = {0.f};
+  float acc2 = 0.f;    // D == 32 / 64 / 128 handled as D/64 full lanes-strides (+ tail for D < 64)
+  for (int s = 0; s < nsp; ++s) {
+    const long pr = (long)s * rows + r;
+    const float w = __expf(pml[pr * 2] - M);
+    L += pml[pr * 2 + 1] * w;
+    if (D >= 64) {
+#pragma unroll
+      for (int c = 0; c < D / 64; ++c) acc[c] += po[pr * D + c * 64 + lane] * w;
+    } else if (lane < D) {
+      acc2 += po[pr * D + lane] * w;
+    }
+  }
+  const float inv = L > 0.f ? 1.f / L : 0.f;
+  if (D >= 64) {
+#pragma unroll
+    for (int c = 0; c < D / 64; ++c) out[(long)r * D + c * 64 + lane] = P::from_f(acc[c] * inv);
+  } else if (lane < D) {
+    out[(long)r * D + lane] = P::from_f(acc2 * inv);
+  }
+}
+
+// partial buffers: po  [max_splits][T][Hq][D] fp32, pml [max_splits][T][Hq][2] fp32
+extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
+                             const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
+                             int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, int dtype,
+                             hipStream_t st) {
+  if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 8 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
+  const int nrows = T * (Hq / Hkv);
+  const int nqt = (nrows + 15) / 16;
+  int qpw = 1;
+  while ((nqt + 4 * qpw - 1) / (4 * qpw) > 64 && qpw < 8) qpw *= 2;
+  const int gz = (nqt + 4 * qpw - 1) / (4 * qpw);
+  const dim3 grid(max_splits, Hkv, gz), block(256);
+  const int rows = T * Hq;
+#define ATT_(DD)                                                                                                  \
+  hipLaunchKernelGGL((tree_attn_kernel<P, DD>), grid, block, 0, st, (const u16*)q, (const u16*)k_cache,            \
+                     (const u16*)vt_cache, (float*)po, (float*)pml, prefix_len,                                    \
+                     (const unsigned long long*)mask_bits, mask_words, n_mask_keys, T, Hq, Hkv, Lmax, chunk, qpw,  \
+                     scale);                                                                                       \
+  hipLaunchKernelGGL((attn_combine_kernel<P, DD>), dim3((rows + 3) / 4), dim3(256), 0, st, (u16*)out,              \
+                     (const float*)po, (const float*)pml, prefix_len, n_mask_keys, chunk, rows)
+  DISPATCH_DTYPE(dtype, {
+    if (D == 128) { ATT_(128); }
+    else if (D == 64) { ATT_(64); }
+    else { ATT_(32); }
+  })
+#undef ATT_
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}

@@ -1,0 +1,232 @@
+// Split-K reduce epilogues fused with the decoder layer's elementwise work.
+// Every kernel reads fp32 partials [S][T][N] written by skinny_gemm_kernel and
+// reduces them in split order 0..S-1 (fixed order -> deterministic).
+//
+// Reference ops fused here (umbrella/models/llama.py:75-114):
+//   residual add + RMSNorm (flashinfer.rmsnorm, model_utils.py:54-64)
+//   SiLU(gate) * up
+//   q/k/v view + RoPE at tree positions (model_utils.py:17-52) + KV append (attn/cache.py:53-65)
+//   embedding gather (F.embedding, llama.py:124)
+#include "common.h"
+
+// ---- plain RMSNorm over rows of 16-bit x (also the standalone umb_rmsnorm op)
+template <typename P>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(u16* __restrict__ out, const u16* __restrict__ x,
+                                                      const u16* __restrict__ w, float eps, int H) {
+  __shared__ float red[4];
+  const int t = blockIdx.x;
+  const u16* xr = x + (long)t * H;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float a = lo_f<P>(v[e]), b = hi_f<P>(v[e]); ss += a * a + b * b; }
+  }
+  ss = block_sum<256>(ss, red);
+  const float inv = rsqrtf(ss / (float)H + eps);
+  for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(w + i);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack2<P>(lo_f<P>(v[e]) * inv * lo_f<P>(g[e]), hi_f<P>(v[e]) * inv * hi_f<P>(g[e]));
+    *reinterpret_cast<u32x4*>(out + (long)t * H + i) = o;
+  }
+}
+
+// ---- h = residual + sum_s partial ; xn = rmsnorm(h) * w   (one block per token row)
+// h_out may alias residual.  xn_out / w may be null (no norm), residual may be null.
+template <typename P>
+__global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* __restrict__ part, int S, int T, int N,
+                                                                   const u16* residual, u16* h_out,
+                                                                   u16* __restrict__ xn_out,
+                                                                   const u16* __restrict__ w, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);            // 4 floats
+  u16* row = reinterpret_cast<u16*>(smem + 16);           // N x u16
+  const int t = blockIdx.x;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 4; i < N; i += 256 * 4) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(part + (long)t * N + i);
+    for (int s = 1; s < S; ++s) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(part + ((long)s * T + t) * N + i);
+      a += b;
+    }
+    // GEMM output is rounded to the model dtype before the residual add (F.linear returns dtype)
+    float v0 = rnd<P>(a[0]), v1 = rnd<P>(a[1]), v2 = rnd<P>(a[2]), v3 = rnd<P>(a[3]);
+    if (residual) {
+      const uint2 r = *reinterpret_cast<const uint2*>(residual + (long)t * N + i);
+      v0 += lo_f<P>(r.x); v1 += hi_f<P>(r.x); v2 += lo_f<P>(r.y); v3 += hi_f<P>(r.y);
+    }
+    uint2 o;
+    o.x = pack2<P>(v0, v1); o.y = pack2<P>(v2, v3);
+    if (h_out) *reinterpret_cast<uint2*>(h_out + (long)t * N + i) = o;
+    *reinterpret_cast<uint2*>(row + i) = o;
+    v0 = lo_f<P>(o.x); v1 = hi_f<P>(o.x); v2 = lo_f<P>(o.y); v3 = hi_f<P>(o.y);
+    ss += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+  }
+  if (!xn_out) return;
+  ss = block_sum<256>(ss, red);
+  const float inv = rsqrtf(ss / (float)N + eps);
+  for (int i = threadIdx.x * 4; i < N; i += 256 * 4) {
+    const uint2 v = *reinterpret_cast<const uint2*>(row + i);
+    const uint2 g = *reinterpret_cast<const uint2*>(w + i);
+    uint2 o;
+    o.x = pack2<P>(lo_f<P>(v.x) * inv * lo_f<P>(g.x), hi_f<P>(v.x) * inv * hi_f<P>(g.x));
+    o.y = pack2<P>(lo_f<P>(v.y) * inv * lo_f<P>(g.y), hi_f<P>(v.y) * inv * hi_f<P>(g.y));
+    *reinterpret_cast<uint2*>(xn_out + (long)t * N + i) = o;
+  }
+}
+
+// ---- act[t][i] = silu(gate) * up ; partial rows hold [gate(0..I) | up(I..2I)]
+template <typename P>
+__global__ __launch_bounds__(256) void reduce_silu_mul_kernel(const float* __restrict__ part, int S, int T, int I,
+                                                              u16* __restrict__ act) {
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (gid >= (long)T * I) return;
+  const int t = (int)(gid / I), i = (int)(gid % I);
+  const int N = 2 * I;
+  f32x4 g = *reinterpret_cast<const f32x4*>(part + (long)t * N + i);
+  f32x4 u = *reinterpret_cast<const f32x4*>(part + (long)t * N + I + i);
+  for (int s = 1; s < S; ++s) {
+    g += *reinterpret_cast<const f32x4*>(part + ((long)s * T + t) * N + i);
+    u += *reinterpret_cast<const f32x4*>(part + ((long)s * T + t) * N + I + i);
+  }
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gg = rnd<P>(g[e]), uu = rnd<P>(u[e]);     // both GEMM outputs live in the model dtype
+    const float sg = rnd<P>(gg / (1.f + __expf(-gg)));    // F.silu in dtype
+    o[e] = sg * uu;
+  }
+  uint2 pk;
+  pk.x = pack2<P>(o[0], o[1]); pk.y = pack2<P>(o[2], o[3]);
+  *reinterpret_cast<uint2*>(act + (long)t * I + i) = pk;
+}
+
+// ---- QKV reduce + RoPE + KV append.  One block per (token, head) with D/2 active pairs.
+// partial row layout: [q (Hq*D) | k (Hkv*D) | v (Hkv*D)]
+// K cache: [Hkv][Lmax][D] ; V cache transposed: [Hkv][D][Lmax]   (layer base pointers)
+template <typename P>
+__global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __restrict__ part, int S, int T, int Hq,
+                                                             int Hkv, int D, int Lmax, const int* __restrict__ pos,
+                                                             const int* __restrict__ slot,
+                                                             const u16* __restrict__ cosT, const u16* __restrict__ sinT,
+                                                             u16* __restrict__ q_out, u16* __restrict__ kc,
+                                                             u16* __restrict__ vt) {
+  const int t = blockIdx.x, head = blockIdx.y;             // head in [0, Hq + 2*Hkv)
+  const int N = (Hq + 2 * Hkv) * D;
+  const int half = D / 2;
+  const int p = pos[t], sl = slot[t];
+  const float* base = part + (long)t * N + head * D;
+  const long sstride = (long)T * N;
+  for (int d = threadIdx.x; d < half; d += 64) {
+    float a = base[d], b = base[d + half];
+    for (int s = 1; s < S; ++s) { a += base[s * sstride + d]; b += base[s * sstride + d + half]; }
+    a = rnd<P>(a); b = rnd<P>(b);
+    if (head < Hq + Hkv) {
+      // rotate-half RoPE in the model dtype (each product and the sum are rounded, as eager torch does)
+      const float c0 = P::to_f(cosT[(long)p * D + d]), c1 = P::to_f(cosT[(long)p * D + d + half]);
+      const float s0 = P::to_f(sinT[(long)p * D + d]), s1 = P::to_f(sinT[(long)p * D + d + half]);
+      const float o0 = rnd<P>(rnd<P>(a * c0) + rnd<P>(-b * s0));
+      const float o1 = rnd<P>(rnd<P>(b * c1) + rnd<P>(a * s1));
+      if (head < Hq) {
+        u16* qo = q_out + ((long)t * Hq + head) * D;
+        qo[d] = P::from_f(o0); qo[d + half] = P::from_f(o1);
+      } else {
+        u16* ko = kc + ((long)(head - Hq) * Lmax + sl) * D;
+        ko[d] = P::from_f(o0); ko[d + half] = P::from_f(o1);
+      }
+    } else {
+      u16* vo = vt + (long)(head - Hq - Hkv) * D * Lmax + sl;
+      vo[(long)d * Lmax] = P::from_f(a);
+      vo[(long)(d + half) * Lmax] = P::from_f(b);
+    }
+  }
+}
+
+// ---- embedding gather + per-forward index prep.
+// TREE mode  (tokens_all != null): token i = tokens_all[n + off + i], pos = n + depth[off+i], slot = n + off + i
+// EXPLICIT   : tokens/pos/slot given; they are copied into the workspace arrays the later kernels read.
+template <typename P>
+__global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, const u16* __restrict__ table, int H,
+                                                         const int* __restrict__ tok_in, const int* __restrict__ pos_in,
+                                                         const int* __restrict__ slot_in,
+                                                         const int* __restrict__ prefix_in,
+                                                         const int* __restrict__ tokens_all,
+                                                         const int* __restrict__ n_ptr, int off,
+                                                         const int* __restrict__ depth, int* __restrict__ pos_out,
+                                                         int* __restrict__ slot_out, int* __restrict__ prefix_out) {
+  const int i = blockIdx.x;
+  int tok, p, s, pre;
+  if (tokens_all) {
+    const int n = *n_ptr;
+    tok = tokens_all[n + off + i]; p = n + depth[off + i]; s = n + off + i; pre = n;
+  } else {
+    tok = tok_in[i]; p = pos_in[i]; s = slot_in[i]; pre = *prefix_in;
+  }
+  if (threadIdx.x == 0) { pos_out[i] = p; slot_out[i] = s; if (i == 0) *prefix_out = pre; }
+  const u32x4* src = reinterpret_cast<const u32x4*>(table + (long)tok * H);
+  u32x4* dst = reinterpret_cast<u32x4*>(x + (long)i * H);
+  for (int k = threadIdx.x; k < H / 8; k += 256) dst[k] = src[k];
+}
+
+// ------------------------------------------------------------------ C entry points
+extern "C" int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype,
+                           hipStream_t st) {
+  if (H % 8 || rows < 1) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((rmsnorm_kernel<P>), dim3(rows), dim3(256), 0, st, (u16*)out, (const u16*)x, (const u16*)w, eps, H);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
+                                        void* xn_out, const void* w, float eps, int dtype, hipStream_t st) {
+  if (N % 4 || T < 1) return UMB_EINVAL;
+  const size_t sm = 16 + (size_t)N * 2;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((reduce_residual_norm_kernel<P>), dim3(T), dim3(256), sm, st, (const float*)partial, S, T, N,
+                       (const u16*)residual, (u16*)h_out, (u16*)xn_out, (const u16*)w, eps);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, hipStream_t st) {
+  if (I % 4) return UMB_EINVAL;
+  const long n4 = (long)T * I / 4;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((reduce_silu_mul_kernel<P>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       (const float*)partial, S, T, I, (u16*)act);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax,
+                                   const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
+                                   void* k_cache, void* vt_cache, int dtype, hipStream_t st) {
+  if (D % 2) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
+                       Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
+                       (u16*)vt_cache);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
+                              const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
+                              int* pos_out, int* slot_out, int* prefix_out, int dtype, hipStream_t st) {
+  if (H % 8 || T < 1) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((embed_prep_kernel<P>), dim3(T), dim3(256), 0, st, (u16*)x, (const u16*)table, H, tok, pos, slot,
+                       prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}

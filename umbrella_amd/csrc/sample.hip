@@ -1,0 +1,365 @@
+// Device-side tree bookkeeping: row arg-max / top-k, Sequoia child placement,
+// SpecExec beam expansion, the accept scan and KV compaction.
+//
+// Reference behaviour restated on the GPU (no host round trips):
+//   target_logits.argmax(-1)                              static_speculation_engine.py:307
+//   sampling_argmax_gather (topk + flatten + gather)      speculation_utils.py:57-61, static:115-123,279-281
+//   beam expand (topk, local log-softmax, global topk)    dynamic_speculation_engine.py:236-248
+//   accept scan + token/num_nodes update + EOS search     static:313-341 / dynamic:283-316
+//   KV_Cache.gather_kv_incremental                        umbrella/attn/cache.py:41-49
+// Ties: the lower vocabulary index wins (torch.argmax semantics).
+#include "common.h"
+
+// key that sorts by (value desc, index asc) when compared as unsigned descending
+__device__ __forceinline__ unsigned long long mk_key(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // monotone float -> uint
+  return ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - idx);
+}
+__device__ __forceinline__ float key_val(unsigned long long k) {
+  unsigned u = (unsigned)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ int key_idx(unsigned long long k) { return 0x7fffffff - (int)(k & 0xffffffffu); }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long x = __shfl_xor(v, o, 64);
+    v = x > v ? x : v;
+  }
+  return v;
+}
+
+// ---- row argmax: one block (1024 threads) per row
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, int V,
+                                                           int* __restrict__ out) {
+  __shared__ unsigned long long red[16];
+  const float* row = logits + (long)blockIdx.x * V;
+  unsigned long long best = 0ull;
+  for (int i = threadIdx.x; i < V; i += 1024) {
+    const unsigned long long k = mk_key(row[i], i);
+    best = k > best ? k : best;
+  }
+  best = wave_max_u64(best);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    unsigned long long b = threadIdx.x < 16 ? red[threadIdx.x] : 0ull;
+    b = wave_max_u64(b);
+    if (threadIdx.x == 0) out[blockIdx.x] = key_idx(b);
+  }
+}
+
+// in-LDS bitonic sort, descending, NT == 1024 threads, n == 1024 keys
+__device__ __forceinline__ void bitonic_desc_1024(unsigned long long* s) {
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      __syncthreads();
+      const int i = threadIdx.x, p = i ^ jj;
+      if (p > i) {
+        const unsigned long long a = s[i], b = s[p];
+        const bool desc = ((i & k) == 0);
+        if (desc ? (a < b) : (a > b)) { s[i] = b; s[p] = a; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ---- row top-k (k <= 64): threshold = k-th largest of the 1024 per-thread maxima, then
+// collect every element >= threshold (>= k of them, few in practice) and sort those.
+// Optionally places the first child_cnt[row] winners as Sequoia children:
+//   tokens_all[n + child_start[row] + r] = idx[r]
+__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict__ logits, int V, int k,
+                                                         int* __restrict__ out_idx, float* __restrict__ out_val,
+                                                         int* __restrict__ tokens_all, const int* __restrict__ n_ptr,
+                                                         const int* __restrict__ child_start,
+                                                         const int* __restrict__ child_cnt) {
+  __shared__ unsigned long long s[1024];
+  __shared__ unsigned long long cand[1024];
+  __shared__ int ncand;
+  const float* row = logits + (long)blockIdx.x * V;
+  unsigned long long best = 0ull;
+  for (int i = threadIdx.x; i < V; i += 1024) {
+    const unsigned long long key = mk_key(row[i], i);
+    best = key > best ? key : best;
+  }
+  s[threadIdx.x] = best;
+  if (threadIdx.x == 0) ncand = 0;
+  bitonic_desc_1024(s);
+  const unsigned long long thr = s[min(k, 1024) - 1];
+  __syncthreads();
+  cand[threadIdx.x] = 0ull;
+  __syncthreads();
+  for (int i = threadIdx.x; i < V; i += 1024) {
+    const unsigned long long key = mk_key(row[i], i);
+    if (key >= thr) {
+      const int slot = atomicAdd(&ncand, 1);
+      if (slot < 1024) cand[slot] = key;
+    }
+  }
+  __syncthreads();
+  const int nc = ncand;
+  if (nc <= 1024) {
+    bitonic_desc_1024(cand);
+  } else {
+    // pathological tie flood: exact but slow fallback, k rounds of block arg-max below the last pick
+    unsigned long long last = ~0ull;
+    for (int r = 0; r < k; ++r) {
+      unsigned long long b = 0ull;
+      for (int i = threadIdx.x; i < V; i += 1024) {
+        const unsigned long long key = mk_key(row[i], i);
+        if (key < last && key > b) b = key;
+      }
+      __syncthreads();
+      s[threadIdx.x] = b;
+      __syncthreads();
+      for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o && s[threadIdx.x + o] > s[threadIdx.x]) s[threadIdx.x] = s[threadIdx.x + o];
+        __syncthreads();
+      }
+      last = s[0];
+      __syncthreads();
+      if (threadIdx.x == 0) cand[r] = last;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < k) {
+    const unsigned long long key = cand[threadIdx.x];
+    const int idx = key_idx(key);
+    if (out_idx) out_idx[(long)blockIdx.x * k + threadIdx.x] = idx;
+    if (out_val) out_val[(long)blockIdx.x * k + threadIdx.x] = key_val(key);
+    if (tokens_all && threadIdx.x < child_cnt[blockIdx.x])
+      tokens_all[*n_ptr + child_start[blockIdx.x] + threadIdx.x] = idx;
+  }
+}
+
+// ---- SpecExec beam expand for one level (single block, 1024 threads; w*B <= 1024)
+// rows = w nodes of the current level at tree offsets [lvl_off, lvl_off+w); their top-B
+// (idx, val) come from topk_rows_kernel.  Children go to tree offsets [lvl_off+w, +W).
+__global__ __launch_bounds__(1024) void beam_expand_kernel(const int* __restrict__ top_idx,
+                                                           const float* __restrict__ top_val, int w, int B, int W,
+                                                           int lvl_off, float* __restrict__ tree_score,
+                                                           int* __restrict__ parents, int* __restrict__ tokens_all,
+                                                           const int* __restrict__ n_ptr,
+                                                           unsigned long long* __restrict__ mask_bits,
+                                                           int mask_words) {
+  __shared__ unsigned long long s[1024];
+  __shared__ float rmax[64], rsum[64];
+  const int tid = threadIdx.x;
+  const int nc = w * B;
+  // local softmax over the B kept logits of each row (dynamic:237)
+  if (tid < w) {
+    float mx = -INFINITY;
+    for (int b = 0; b < B; ++b) mx = fmaxf(mx, top_val[tid * B + b]);
+    float sm = 0.f;
+    for (int b = 0; b < B; ++b) sm += expf(top_val[tid * B + b] - mx);
+    rmax[tid] = mx; rsum[tid] = sm;
+  }
+  __syncthreads();
+  float score = -INFINITY;
+  if (tid < nc) {
+    const int r = tid / B;
+    const float p = expf(top_val[tid] - rmax[r]) / rsum[r];
+    score = tree_score[lvl_off + r] + logf(p + 1e-4f);
+  }
+  // candidate order key: (score desc, flat index asc)
+  s[tid] = tid < nc ? mk_key(score, tid) : 0ull;
+  bitonic_desc_1024(s);
+  if (tid < W) {
+    const unsigned long long key = s[tid];
+    const int flat = key_idx(key);
+    const int par = flat / B;                       // row within the level
+    const int child = lvl_off + w + tid;            // tree offset of the new node
+    tree_score[child] = key_val(key);
+    tokens_all[*n_ptr + child] = top_idx[flat];
+    parents[child] = lvl_off + par;
+    // mask row = parent's row | own bit  (dynamic:247-248)
+    for (int mw = 0; mw < mask_words; ++mw) {
+      unsigned long long v = mask_bits[(long)(lvl_off + par) * mask_words + mw];
+      if ((child >> 6) == mw) v |= 1ull << (child & 63);
+      mask_bits[(long)child * mask_words + mw] = v;
+    }
+  }
+}
+
+// ---- accept scan (single block of 1024 threads, T <= 1024)
+// out[0] = accepted count kept in the KV (after EOS truncation), out[1] = bonus token,
+// out[2] = 1 if an EOS token was hit, out[3] = new num_nodes, out[4] = raw accept length
+// path[i] = tree index of the i-th accepted node (root first)
+__global__ __launch_bounds__(1024) void accept_scan_kernel(const int* __restrict__ sampled,
+                                                           const int* __restrict__ parents,
+                                                           int* __restrict__ tokens_all, int* __restrict__ n_ptr,
+                                                           int T, const int* __restrict__ eos, int n_eos,
+                                                           int* __restrict__ out, int* __restrict__ path) {
+  __shared__ int wcount[16];
+  __shared__ int spath[1024];
+  __shared__ int s_a, first_hit;
+  const int tid = threadIdx.x;
+  const int n = *n_ptr;
+  int ok = 0;
+  if (tid < T) {
+    // node is on the path iff every node on the root..tid chain matches its parent's sample
+    ok = 1;
+    int c = tid;
+    while (c != 0) {
+      const int p = parents[c];
+      if (sampled[p] != tokens_all[n + c]) { ok = 0; break; }
+      c = p;
+    }
+  }
+  // ordered compaction (== nonzero()): ballot + popcount prefix
+  const unsigned long long bal = __ballot(ok);
+  const int lane = tid & 63, wv = tid >> 6;
+  if (lane == 0) wcount[wv] = __popcll(bal);
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < wv; ++i) base += wcount[i];
+  if (ok) spath[base + __popcll(bal & ((1ull << lane) - 1ull))] = tid;
+  if (tid == 0) {
+    int a = 0;
+    for (int i = 0; i < 16; ++i) a += wcount[i];
+    s_a = a; first_hit = 0x7fffffff;
+  }
+  __syncthreads();
+  const int a = s_a;
+  const int bonus = sampled[spath[a - 1]];
+  // tokens[n + i] = spec[path[i]] (i < a) ; tokens[n + a] = bonus.  Read everything first: sources overlap destinations.
+  int mytok = 0, hit = 0;
+  if (tid < a) mytok = tokens_all[n + spath[tid]];
+  else if (tid == a) mytok = bonus;
+  if (tid <= a)
+    for (int e = 0; e < n_eos; ++e) hit |= (mytok == eos[e]);
+  __syncthreads();
+  if (tid <= a) tokens_all[n + tid] = mytok;
+  if (hit) atomicMin(&first_hit, tid);            // first EOS among accepted + bonus (static:329-341)
+  __syncthreads();
+  const int e = first_hit;
+  const int keep = (e != 0x7fffffff) ? e : a;
+  if (tid < keep) path[tid] = spath[tid];
+  if (tid == 0) {
+    out[0] = keep; out[1] = bonus; out[2] = (e != 0x7fffffff); out[3] = n + keep; out[4] = a;
+    *n_ptr = n + keep;
+  }
+}
+
+// ---- KV compaction: slot n_old + path[i] -> n_old + i for i in [1, keep).  One block per
+// (kv head, layer); all sources are staged in LDS before any destination is written.
+template <int D>
+__global__ __launch_bounds__(256) void kv_compact_kernel(u16* __restrict__ kc, u16* __restrict__ vt,
+                                                         const int* __restrict__ res, const int* __restrict__ path,
+                                                         int Hkv, int Lmax, int max_path) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u16* sk = reinterpret_cast<u16*>(smem);                   // [max_path][D]
+  u16* sv = sk + (long)max_path * D;                        // [max_path][D]
+  const int keep = min(res[0], max_path);
+  if (keep <= 1) return;
+  const int n_old = res[3] - res[0];
+  const int h = blockIdx.x, layer = blockIdx.y;
+  u16* kb = kc + ((long)layer * Hkv + h) * Lmax * D;
+  u16* vb = vt + ((long)layer * Hkv + h) * D * Lmax;
+  const int total = keep * D;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int i = e / D, d = e % D;
+    const int src = n_old + path[i];
+    sk[e] = kb[(long)src * D + d];
+    sv[e] = vb[(long)d * Lmax + src];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int i = e / D, d = e % D;
+    if (path[i] == i) continue;
+    kb[(long)(n_old + i) * D + d] = sk[e];
+    vb[(long)d * Lmax + n_old + i] = sv[e];
+  }
+}
+
+// ---- misc tiny kernels
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void mask_eos_last_row_kernel(float* logits_last_row, const int* eos, int n_eos) {
+  if ((int)threadIdx.x < n_eos) logits_last_row[eos[threadIdx.x]] = -INFINITY;
+}
+__global__ void write_token_kernel(int* tokens_all, const int* n_ptr, const int* src) { tokens_all[*n_ptr] = src[0]; }
+
+// bench / test knob: force chosen tree slots to given tokens (tbl[i] < 0 keeps the drafted token)
+__global__ void apply_override_kernel(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt) {
+  const int i = threadIdx.x + blockIdx.x * blockDim.x;
+  if (i < cnt && tbl[off + i] >= 0) tokens_all[*n_ptr + off + i] = tbl[off + i];
+}
+
+// ------------------------------------------------------------------ C entry points
+extern "C" int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt, hipStream_t st) {
+  if (cnt < 1) return UMB_OK;
+  hipLaunchKernelGGL(apply_override_kernel, dim3((cnt + 63) / 64), dim3(64), 0, st, tokens_all, n_ptr, tbl, off, cnt);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_argmax_rows(int* out, const float* logits, int rows, int V, hipStream_t st) {
+  if (rows < 1) return UMB_EINVAL;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, st, logits, V, out);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_topk_rows(int* out_idx, float* out_val, const float* logits, int rows, int V, int k,
+                             int* tokens_all, const int* n_ptr, const int* child_start, const int* child_cnt,
+                             hipStream_t st) {
+  if (rows < 1 || k < 1 || k > 64 || V < k) return UMB_EINVAL;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(1024), 0, st, logits, V, k, out_idx, out_val, tokens_all, n_ptr,
+                     child_start, child_cnt);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_beam_expand(const int* top_idx, const float* top_val, int w, int B, int W, int lvl_off,
+                               float* tree_score, int* parents, int* tokens_all, const int* n_ptr, void* mask_bits,
+                               int mask_words, hipStream_t st) {
+  if (w * B > 1024 || W > w * B || w > 64) return UMB_EINVAL;
+  hipLaunchKernelGGL(beam_expand_kernel, dim3(1), dim3(1024), 0, st, top_idx, top_val, w, B, W, lvl_off, tree_score,
+                     parents, tokens_all, n_ptr, (unsigned long long*)mask_bits, mask_words);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_accept_scan(const int* sampled, const int* parents, int* tokens_all, int* n_ptr, int T,
+                               const int* eos, int n_eos, int* out5, int* path, hipStream_t st) {
+  if (T < 1 || T > 1024) return UMB_EINVAL;
+  hipLaunchKernelGGL(accept_scan_kernel, dim3(1), dim3(1024), 0, st, sampled, parents, tokens_all, n_ptr, T, eos, n_eos,
+                     out5, path);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_kv_compact(void* k_cache, void* vt_cache, const int* res, const int* path, int L, int Hkv, int D,
+                              int Lmax, int max_path, int dtype_unused, hipStream_t st) {
+  const size_t sm = (size_t)max_path * D * 2 * 2;
+  const dim3 grid(Hkv, L), block(256);
+  if (D == 128) hipLaunchKernelGGL((kv_compact_kernel<128>), grid, block, sm, st, (u16*)k_cache, (u16*)vt_cache, res, path, Hkv, Lmax, max_path);
+  else if (D == 64) hipLaunchKernelGGL((kv_compact_kernel<64>), grid, block, sm, st, (u16*)k_cache, (u16*)vt_cache, res, path, Hkv, Lmax, max_path);
+  else if (D == 32) hipLaunchKernelGGL((kv_compact_kernel<32>), grid, block, sm, st, (u16*)k_cache, (u16*)vt_cache, res, path, Hkv, Lmax, max_path);
+  else return UMB_EINVAL;
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_set_int(int* p, int v, hipStream_t st) {
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, p, v);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_mask_eos(float* logits_row, const int* eos, int n_eos, hipStream_t st) {
+  if (n_eos > 64) return UMB_EINVAL;
+  hipLaunchKernelGGL(mask_eos_last_row_kernel, dim3(1), dim3(64), 0, st, logits_row, eos, n_eos);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_write_token(int* tokens_all, const int* n_ptr, const int* src, hipStream_t st) {
+  hipLaunchKernelGGL(write_token_kernel, dim3(1), dim3(1), 0, st, tokens_all, n_ptr, src);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}

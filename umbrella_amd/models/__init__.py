@@ -1,0 +1,1 @@
+from .auto_model import AutoModelLM  # noqa: F401

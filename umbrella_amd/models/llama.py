@@ -1,0 +1,428 @@
+"""Llama model runtime on the HIP hot path.
+
+Mirrors the reference's model-runtime face (umbrella/models/base.py:4-32,
+umbrella/models/llama.py): ``alloc(**kw)``, ``inference(input_ids, position_ids,
+attention_mask, storage_ids) -> fp32 logits [1,T,V]``, ``graph_inference``,
+``gather_kv_incremental(indices, offset)``, ``clear()``, attrs ``config`` /
+``kv_cache``.  One class covers the reference's five Llama variants:
+
+  Llama / LlamaAwq        resident weights (dense 16-bit or AWQ int4 tiles)
+  LlamaOffload / AwqOffload  ``offload=True``: layer slabs in pinned host DRAM streamed through two
+                          device slabs on a side stream (event ordered, one hipMemcpyAsync per layer)
+  LlamaCudagraph          ``cuda_graph=True``: honours ``exit_layer``; step graphs are captured by the engine
+
+Everything numeric runs in libumbrella_hip.so (see include/umbrella_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import torch
+
+from .. import _lib
+from .._lib import UmbLayer, UmbLinear, UmbModel, UmbOffload, UmbStep, UmbWorkspace
+from ..attn.cache import TreeKVCache
+from .base import LLMBase
+from .config import KNOWN, LlamaCfg, rope_tables
+from .synthetic import LINEARS, linear_shapes, synth_awq_tensors, synth_tensor
+
+
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+class PackedLinear:
+    """One linear layer in MFMA tile order (dense 16-bit or AWQ int4)."""
+
+    def __init__(self, N, K, awq, w, meta, force_s1=False):
+        self.N, self.K, self.awq, self.w, self.meta = N, K, int(awq), w, meta
+        R, S = C.c_int(0), C.c_int(0)
+        _lib.load().umb_gemm_plan(N, K, self.awq, int(force_s1), C.byref(R), C.byref(S))
+        self.R, self.S = R.value, S.value
+
+    @staticmethod
+    def packed_bytes(N, K, awq):
+        if awq:
+            return _align(N * K // 2), _align((N // 16) * (K // 128) * 48)
+        return _align(N * K * 2), 0
+
+    @classmethod
+    def from_dense(cls, w: torch.Tensor, out=None, force_s1=False):
+        """w [N, K] fp16/bf16 on the GPU (HF row-major)."""
+        N, K = w.shape
+        assert N % 16 == 0 and K % 128 == 0, (N, K)
+        w = w.contiguous()
+        buf = out if out is not None else torch.empty(N * K * 2, dtype=torch.uint8, device=w.device)
+        _lib.call("umb_repack_dense", buf, w, N, K, _lib.dtype_code(w.dtype))
+        return cls(N, K, False, buf, None, force_s1)
+
+    @classmethod
+    def from_awq(cls, qweight, qzeros, scales, group=128, out_w=None, out_meta=None):
+        """AutoAWQ GEMM tensors on the GPU: qweight [K, N/8] i32, qzeros [K/G, N/8] i32, scales [K/G, N] fp16."""
+        K, N = qweight.shape[0], qweight.shape[1] * 8
+        assert N % 16 == 0 and K % 128 == 0 and group == 128, (N, K, group)
+        wb, mb = cls.packed_bytes(N, K, True)
+        w = out_w if out_w is not None else torch.empty(wb, dtype=torch.uint8, device=qweight.device)
+        meta = out_meta if out_meta is not None else torch.empty(mb, dtype=torch.uint8, device=qweight.device)
+        _lib.call("umb_awq_repack", w, meta, qweight.contiguous(), qzeros.contiguous(),
+                  scales.to(torch.float16).contiguous(), N, K, group)
+        return cls(N, K, True, w, meta)
+
+    def struct(self, w_ptr=None, meta_ptr=None) -> UmbLinear:
+        s = UmbLinear()
+        s.w = self.w.data_ptr() if w_ptr is None else w_ptr
+        s.meta = (self.meta.data_ptr() if self.meta is not None else 0) if meta_ptr is None else meta_ptr
+        s.N, s.K, s.awq, s.R, s.S = self.N, self.K, self.awq, self.R, self.S
+        return s
+
+    def apply(self, x: torch.Tensor, round_out=False) -> torch.Tensor:
+        """x [T, K] 16-bit -> fp32 [T, N] (split-K partials summed in split order)."""
+        T = x.shape[0]
+        part = torch.empty(self.S, T, self.N, dtype=torch.float32, device=x.device)
+        _lib.call("umb_gemm", part, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, self.S, self.R,
+                  int(round_out), _lib.dtype_code(x.dtype))
+        out = part[0]
+        for s in range(1, self.S):
+            out = out + part[s]
+        return out
+
+
+def pack_mask_bits(mask: torch.Tensor) -> torch.Tensor:
+    """bool [T, C] -> int64 [T, ceil(C/64)] little-endian bit words (bit b of word w = column 64w+b)."""
+    T, Cn = mask.shape
+    W = (Cn + 63) // 64
+    m = torch.zeros(T, W * 64, dtype=torch.int64, device=mask.device)
+    m[:, :Cn] = mask.to(torch.int64)
+    sh = torch.arange(64, device=mask.device, dtype=torch.int64)
+    return (m.view(T, W, 64) << sh).sum(dim=-1)     # wraps into the sign bit as intended
+
+
+class Llama(LLMBase):
+    CHUNK = 64          # tokens per forward on the generic / prefill path
+
+    def __init__(self, model_name: str, batch_size: int = 1, max_length: int = 256, device: str = "cuda:0",
+                 dtype=torch.float16, offload: bool = False, cuda_graph: bool = False, state_dict=None,
+                 config: LlamaCfg | None = None, seed: int = 0) -> None:
+        super().__init__()
+        assert batch_size == 1, "the hot path is batch 1 (README.md:22)"
+        self.model_name, self.batch_size, self.device, self.dtype = model_name, batch_size, device, dtype
+        self.max_length = (max_length + 31) // 32 * 32
+        self.offload, self.cuda_graph = offload, cuda_graph
+        self._state, self._seed = state_dict, seed
+        if config is not None:
+            self.config = config
+        elif os.path.isdir(model_name):
+            self.config = LlamaCfg.from_dir(model_name)
+        elif model_name in KNOWN:
+            self.config = KNOWN[model_name]
+        else:
+            raise ValueError(f"Model type '{model_name}' is not supported. Supported types: {list(KNOWN.keys())} "
+                             "or a local directory with config.json")
+        c = self.config
+        self.hidden_size, self.num_heads, self.head_dim = c.hidden_size, c.num_attention_heads, c.head_dim
+        self.num_key_value_heads = c.num_key_value_heads
+        self.eos_tokens = list(c.eos_token_id)
+        self.ws_tokens = 0
+
+    # ------------------------------------------------------------------ weights
+    def _tensor_source(self):
+        """name -> device tensor fetcher: given state dict, local safetensors, or seeded synthetic."""
+        c, dev = self.config, self.device
+        if self._state is not None:
+            sd = self._state
+            return lambda name, shape, kind: sd[name].to(dev)
+        if os.path.isdir(self.model_name):
+            from safetensors import safe_open
+            files = [os.path.join(self.model_name, f) for f in sorted(os.listdir(self.model_name)) if f.endswith(".safetensors")]
+            index = {}
+            for f in files:
+                with safe_open(f, "pt") as h:
+                    for k in h.keys():
+                        index[k] = f
+
+            def fetch(name, shape, kind):
+                if name == "lm_head.weight" and name not in index:
+                    name = "model.embed_tokens.weight"
+                with safe_open(index[name], "pt") as h:
+                    return h.get_tensor(name).to(dev)
+            return fetch
+        if os.environ.get("UMBRELLA_SYNTHETIC", "1") != "1":
+            raise FileNotFoundError(f"no checkpoint for {self.model_name} and UMBRELLA_SYNTHETIC=0")
+        gen = torch.Generator(device=dev).manual_seed(self._seed)
+
+        def synth(name, shape, kind):
+            if kind == "norm":
+                return torch.ones(shape, dtype=self.dtype, device=dev)
+            if kind == "embed":
+                return synth_tensor(shape, 1.0, self.dtype, dev, gen)
+            return synth_tensor(shape, 0.02 if kind == "linear" else 0.05, self.dtype, dev, gen)
+        synth.gen = gen
+        return synth
+
+    def _load_linear_group(self, fetch, prefix, names, slab, cursor):
+        """Fuse `names` (HF linear names) along N, pack into `slab` at `cursor`; returns (PackedLinear, cursor)."""
+        c = self.config
+        shapes = linear_shapes(c)
+        N = sum(shapes[n][0] for n in names)
+        K = shapes[names[0]][1]
+        wb, mb = PackedLinear.packed_bytes(N, K, c.awq)
+        w_view = slab[cursor:cursor + (N * K // 2 if c.awq else N * K * 2)]
+        meta_view = slab[cursor + wb:cursor + wb + (N // 16) * (K // 128) * 48] if c.awq else None
+        if c.awq:
+            parts = []
+            for n in names:
+                base = prefix + n
+                if getattr(fetch, "gen", None) is not None:
+                    parts.append(synth_awq_tensors(shapes[n][0], K, c.awq_group, self.device, fetch.gen))
+                else:
+                    parts.append((fetch(base + ".qweight", None, "q"), fetch(base + ".qzeros", None, "q"),
+                                  fetch(base + ".scales", None, "q")))
+            qw = torch.cat([p[0] for p in parts], dim=1)
+            qz = torch.cat([p[1] for p in parts], dim=1)
+            sc = torch.cat([p[2] for p in parts], dim=1)
+            lin = PackedLinear.from_awq(qw, qz, sc, c.awq_group, out_w=w_view, out_meta=meta_view)
+        else:
+            w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
+            lin = PackedLinear.from_dense(w, out=w_view)
+        lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
+        return lin, cursor + wb + mb
+
+    def alloc(self, **kwargs):
+        c, dev, dt = self.config, self.device, self.dtype
+        _lib.load()
+        exit_layer = kwargs.pop("exit_layer", -1)
+        self.num_cache_layers = kwargs.get("num_cache_layers", 0)
+        L = c.num_hidden_layers
+        if self.cuda_graph and exit_layer and exit_layer > 0:          # llama.py:421,450-451
+            L = min(L, exit_layer)
+        self.num_layers = L
+        fetch = self._tensor_source()
+        H, V = c.hidden_size, c.vocab_size
+        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed").to(dt).contiguous()
+        head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head").to(dt)
+        self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)
+        del head_w
+        self.norm_weight = fetch("model.norm.weight", (H,), "norm").to(dt).contiguous()
+        self.cos_cache, self.sin_cache = (t.to(dev).contiguous() for t in rope_tables(c, self.max_length, dt))
+        self.kv_cache = TreeKVCache(L, c.num_key_value_heads, c.head_dim, self.max_length, dev, dt)
+
+        groups = (("qkv", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj")), ("o", ("self_attn.o_proj",)),
+                  ("gu", ("mlp.gate_proj", "mlp.up_proj")), ("down", ("mlp.down_proj",)))
+        shapes = linear_shapes(c)
+        slab_bytes = 0
+        for _, names in groups:
+            wb, mb = PackedLinear.packed_bytes(sum(shapes[n][0] for n in names), shapes[names[0]][1], c.awq)
+            slab_bytes += wb + mb
+        self.slab_bytes = slab_bytes
+        self.layers, self.slabs, self.host_slabs, self.norms = [], [], [], []
+        self._layer_structs = (UmbLayer * L)()
+        stream_any = False
+        for i in range(L):
+            p = f"model.layers.{i}."
+            slab = torch.empty(slab_bytes, dtype=torch.uint8, device=dev)
+            cursor, lins = 0, {}
+            for key, names in groups:
+                lins[key], cursor = self._load_linear_group(fetch, p, names, slab, cursor)
+            n1 = fetch(p + "input_layernorm.weight", (H,), "norm").to(dt).contiguous()
+            n2 = fetch(p + "post_attention_layernorm.weight", (H,), "norm").to(dt).contiguous()
+            self.norms.append((n1, n2))
+            streamed = self.offload and i >= self.num_cache_layers
+            ls = self._layer_structs[i]
+            for key in ("qkv", "o", "gu", "down"):
+                ln = lins[key]
+                if streamed:      # offsets (+1 so 0 stays NULL) relative to the streamed slab base
+                    setattr(ls, key, ln.struct(w_ptr=ln.off_w + 1, meta_ptr=(ln.off_meta + 1) if ln.off_meta is not None else 0))
+                else:
+                    setattr(ls, key, ln.struct())
+            ls.norm1, ls.norm2 = n1.data_ptr(), n2.data_ptr()
+            if streamed:
+                host = torch.empty(slab_bytes, dtype=torch.uint8, pin_memory=True)
+                host.copy_(slab)
+                self.host_slabs.append(host)
+                self.slabs.append(None)
+                for ln in lins.values():
+                    ln.w = ln.meta = None
+                stream_any = True
+                del slab
+            else:
+                self.host_slabs.append(None)
+                self.slabs.append(slab)
+            self.layers.append(lins)
+        self._plans = {k: (self.layers[0][k].N, self.layers[0][k].K, self.layers[0][k].S) for k in self.layers[0]}
+        self._m = UmbModel()
+        m = self._m
+        m.dtype, m.L, m.H, m.I, m.Hq, m.Hkv, m.D, m.V, m.Lmax = (_lib.dtype_code(dt), L, H, c.intermediate_size,
+                                                               c.num_attention_heads, c.num_key_value_heads,
+                                                               c.head_dim, V, self.max_length)
+        m.eps, m.attn_scale = c.rms_norm_eps, 1.0 / math.sqrt(c.head_dim)
+        m.embed, m.lm_head, m.final_norm = self.embed_tokens.data_ptr(), self.lm_head.struct(), self.norm_weight.data_ptr()
+        m.rope_cos, m.rope_sin = self.cos_cache.data_ptr(), self.sin_cache.data_ptr()
+        m.k_cache, m.vt_cache = self.kv_cache.k.data_ptr(), self.kv_cache.vt.data_ptr()
+        m.layers = C.cast(self._layer_structs, C.POINTER(UmbLayer))
+        self._off = None
+        if stream_any:
+            self._dev_slabs = [torch.empty(slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.load_stream = torch.cuda.Stream(device=dev)
+            self._events = [torch.cuda.Event() for _ in range(4)]
+            for e in self._events:
+                e.record()                 # materialise the hipEvent_t handles
+            arr = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in self.host_slabs])
+            self._host_arr = arr
+            off = UmbOffload()
+            off.host_slabs = C.cast(arr, C.POINTER(C.c_void_p))
+            off.slab_bytes = slab_bytes
+            off.dev_slab[0], off.dev_slab[1] = self._dev_slabs[0].data_ptr(), self._dev_slabs[1].data_ptr()
+            off.copy_stream = self.load_stream.cuda_stream
+            off.ev_copied[0], off.ev_copied[1] = self._events[0].cuda_event, self._events[1].cuda_event
+            off.ev_free[0], off.ev_free[1] = self._events[2].cuda_event, self._events[3].cuda_event
+            self._off = off
+        self.reserve(self.CHUNK)
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ workspace
+    def reserve(self, tokens: int):
+        """Size the activation workspace for forwards of up to `tokens` rows."""
+        if tokens <= self.ws_tokens:
+            return
+        c, dev, dt = self.config, self.device, self.dtype
+        T = tokens
+        H, I, QD, V = c.hidden_size, c.intermediate_size, c.q_dim, c.vocab_size
+        self.ws_tokens = T
+        w = self._bufs = {}
+        w["h"] = torch.zeros(T, H, dtype=dt, device=dev)
+        w["xn"] = torch.zeros(T, H, dtype=dt, device=dev)
+        w["q"] = torch.zeros(T, QD, dtype=dt, device=dev)
+        w["attn"] = torch.zeros(T, QD, dtype=dt, device=dev)
+        w["act"] = torch.zeros(T, I, dtype=dt, device=dev)
+        part = max(S * T * N for (N, K, S) in self._plans.values())
+        w["partial"] = torch.empty(part, dtype=torch.float32, device=dev)
+        self.attn_chunk = max(256, (self.max_length // 8 + 31) // 32 * 32)
+        self.attn_splits = (self.max_length + self.attn_chunk - 1) // self.attn_chunk
+        w["po"] = torch.empty(self.attn_splits * T * QD, dtype=torch.float32, device=dev)
+        w["ml"] = torch.empty(self.attn_splits * T * c.num_attention_heads * 2, dtype=torch.float32, device=dev)
+        w["pos"] = torch.zeros(T, dtype=torch.int32, device=dev)
+        w["slot"] = torch.zeros(T, dtype=torch.int32, device=dev)
+        w["prefix"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        w["logits"] = torch.empty(T, V, dtype=torch.float32, device=dev)
+        ws = self._ws = UmbWorkspace()
+        ws.h, ws.xn, ws.q, ws.attn, ws.act = (w[k].data_ptr() for k in ("h", "xn", "q", "attn", "act"))
+        ws.partial, ws.attn_po, ws.attn_ml = w["partial"].data_ptr(), w["po"].data_ptr(), w["ml"].data_ptr()
+        ws.pos, ws.slot, ws.prefix, ws.logits = (w[k].data_ptr() for k in ("pos", "slot", "prefix", "logits"))
+        ws.Tmax, ws.attn_chunk, ws.attn_splits = T, self.attn_chunk, self.attn_splits
+
+    @property
+    def logits_buffer(self) -> torch.Tensor:
+        return self._bufs["logits"]
+
+    @property
+    def hidden_buffer(self) -> torch.Tensor:
+        return self._bufs["h"]
+
+    # ------------------------------------------------------------------ forward
+    def _run(self, step: UmbStep):
+        lib = _lib.load()
+        st = _lib.stream_ptr()
+        if self._off is not None:
+            rc = lib.umb_model_forward_offload(C.byref(self._m), C.byref(self._ws), C.byref(step), C.byref(self._off), st)
+        else:
+            rc = lib.umb_model_forward(C.byref(self._m), C.byref(self._ws), C.byref(step), st)
+        _lib.check(rc, "umb_model_forward")
+
+    def forward_tree(self, tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=0,
+                     layer_range=None, skip_embed=False):
+        """Tree-mode step: rows are tree nodes [tree_off, tree_off+T) of the engine's token buffer; all
+        run-time indices derive from the device scalar *n_ptr (graph-capturable)."""
+        s = UmbStep()
+        s.T, s.tree_off = T, tree_off
+        s.tokens_all, s.n_ptr, s.depth = tokens_all.data_ptr(), n_ptr.data_ptr(), depth.data_ptr()
+        s.mask_bits = mask_bits.data_ptr() + tree_off * mask_words * 8
+        s.mask_words, s.n_mask_keys = mask_words, tree_off + T
+        s.head_from = head_from
+        s.layer_begin, s.layer_end = layer_range or (0, self.num_layers)
+        s.skip_embed = int(skip_embed)
+        self._run(s)
+
+    def forward_explicit(self, tokens, positions, slots, prefix_len, mask_bits=None, mask_words=0, n_mask_keys=None,
+                         head_from=0, layer_range=None, skip_embed=False):
+        """Explicit-mode step: int32 device arrays tokens/positions/slots [T], prefix_len int32[1]."""
+        T = tokens.shape[0]
+        s = UmbStep()
+        s.T = T
+        s.tokens, s.positions, s.slots = tokens.data_ptr(), positions.data_ptr(), slots.data_ptr()
+        s.prefix_len = prefix_len.data_ptr()
+        s.mask_bits = mask_bits.data_ptr() if mask_bits is not None else 0
+        s.mask_words = mask_words
+        s.n_mask_keys = T if n_mask_keys is None else n_mask_keys
+        s.head_from = head_from
+        s.layer_begin, s.layer_end = layer_range or (0, self.num_layers)
+        s.skip_embed = int(skip_embed)
+        self._keep = (tokens, positions, slots, prefix_len, mask_bits)
+        self._run(s)
+
+    @torch.inference_mode()
+    def prefill_tokens(self, ids: torch.Tensor, start: int, want_logits=True):
+        """Causal forward over ids (int32 [P], device) placed at slots/positions start.. ; returns the
+        fp32 logits row of the last token (view into the workspace) if requested."""
+        P = ids.shape[0]
+        dev = self.device
+        out = None
+        for lo in range(0, P, self.CHUNK):
+            hi = min(P, lo + self.CHUNK)
+            T = hi - lo
+            pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=dev)
+            pre = torch.tensor([start + lo], dtype=torch.int32, device=dev)
+            last = hi == P and want_logits
+            self.forward_explicit(ids[lo:hi].contiguous(), pos, pos, pre, head_from=(T - 1 if last else T))
+            if last:
+                out = self._bufs["logits"][0]
+        self.kv_cache.kv_offset = start + P
+        return out
+
+    @torch.inference_mode()
+    def inference(self, input_ids: torch.LongTensor, position_ids: torch.LongTensor, attention_mask: torch.Tensor,
+                  storage_ids: torch.LongTensor):
+        """Reference face (umbrella/models/llama.py:117-134).  attention_mask: bool [T, >= kv] (True = attend);
+        columns are cache slots.  Rows may only attend slots that were written before or by this call."""
+        dev = self.device
+        ids = input_ids.reshape(-1).to(device=dev, dtype=torch.int32)
+        pos = position_ids.reshape(-1).to(device=dev, dtype=torch.int32)
+        slots = storage_ids.reshape(-1).to(device=dev, dtype=torch.int32)
+        mask = attention_mask.to(dev)
+        T = ids.shape[0]
+        allrows = mask.all(dim=0).to(torch.int32)
+        prefix = int(allrows.cumprod(0).sum().item())                    # leading columns every row attends
+        anyc = mask.any(dim=0).nonzero()
+        kv_end = int(anyc[-1].item()) + 1 if anyc.numel() else prefix
+        nmk = max(kv_end - prefix, 1)
+        bits = pack_mask_bits(mask[:, prefix:prefix + nmk])
+        W = bits.shape[1]
+        pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
+        V = self.config.vocab_size
+        out = torch.empty(T, V, dtype=torch.float32, device=dev)
+        for lo in range(0, T, self.ws_tokens):
+            hi = min(T, lo + self.ws_tokens)
+            self.forward_explicit(ids[lo:hi].contiguous(), pos[lo:hi].contiguous(), slots[lo:hi].contiguous(), pre,
+                                  mask_bits=bits[lo:hi].contiguous(), mask_words=W, n_mask_keys=nmk, head_from=0)
+            out[lo:hi] = self._bufs["logits"][:hi - lo]
+        self.kv_cache.kv_offset = max(self.kv_cache.kv_offset, int(slots.max().item()) + 1)
+        return out[None]
+
+    def graph_inference(self, input_ids, storage_ids, position_ids=None, attention_mask=None):
+        return self.inference(input_ids, position_ids, attention_mask, storage_ids)
+
+    def gather_kv_incremental(self, indices: torch.LongTensor, offset: int):
+        self.kv_cache.gather_kv_incremental(indices, offset)
+
+    def clear(self):
+        self.kv_cache.clear()
+
+    # bytes read from HBM by one forward over all layers + lm_head (algorithmic, for the roofline)
+    def weight_bytes(self) -> int:
+        c = self.config
+        per_layer = 0
+        for lins in self.layers[:1]:
+            for ln in lins.values():
+                per_layer += (ln.N * ln.K // 2 + (ln.N // 16) * (ln.K // 128) * 48) if ln.awq else ln.N * ln.K * 2
+        return per_layer * self.num_layers + self.lm_head.N * self.lm_head.K * 2

@@ -1,0 +1,76 @@
+"""Sequoia growmap construction (replaces umbrella/sequoia_utils.py:40-130).
+
+``generate_sequoia_tree(width, depth, acc)`` grows the tree level by level, keeping at
+every level the `width` (parent, rank) candidates with the highest accumulated
+log-acceptance; the JSON schema (roots / branches / Successors / mask / depth / size)
+is the one the engines and the reference's shipped trees use.
+"""
+from __future__ import annotations
+
+import heapq
+import json
+import math
+
+DEFAULT_ACC = [0.65, 0.2, 0.1, 0.05]
+
+
+def successor_list_to_mask(successors):
+    n = len(successors)
+    parent = [-1] * n
+    for p, kids in enumerate(successors):
+        for c in kids:
+            parent[c] = p
+    rows = []
+    for i in range(n):
+        row = [0] * n
+        j = i
+        while j != -1:
+            row[j] = 1
+            j = parent[j]
+        rows.append(row)
+    return rows
+
+
+def generate_sequoia_tree(width: int, depth: int, acc=None, json_file=None):
+    if acc is None:
+        assert width <= 4, "Using default acceptance rate vector, require width<=4"
+        acc = DEFAULT_ACC
+    import torch
+    lacc = torch.log(torch.tensor(acc, dtype=torch.float32))
+    nb = len(lacc)
+    roots, branches, succ, tdepth = [[0]], [[0]], [[]], [0]
+    scores = torch.zeros(1, dtype=torch.float32)
+    for lvl in range(depth):
+        first = lvl * width + 1
+        roots.append(list(range(first, first + width)))
+        branches.append([0] * width)
+        tdepth += [lvl + 1] * width
+        succ += [[] for _ in range(width)]
+        cand = (lacc[None, :] + scores[:, None]).reshape(-1)                          # (parent, rank) flattened
+        # torch.topk decides ties (three-way ties occur with the default vector); the shipped
+        # growmaps were produced with it, so the selection rule is part of the data format
+        new_scores, order = cand.topk(k=width)
+        base = 0 if lvl == 0 else (lvl - 1) * width + 1
+        pars = sorted(int(i) // nb + base for i in order)
+        for child, par in enumerate(pars):
+            succ[par].append(first + child)
+            branches[lvl][par - base] += 1
+        scores = new_scores
+    out = {"roots": roots, "branches": branches, "Successors": succ, "mask": successor_list_to_mask(succ),
+           "depth": tdepth, "size": width * depth + 1}
+    if json_file is not None:
+        with open(json_file, "w") as f:
+            json.dump(out, f, indent=4)
+    return out
+
+
+def expected_accept_length(growmap: dict, acc) -> float:
+    """E[#accepted tokens per verify] (root + bonus counted as in the engines' dec_len/steps)
+    if the rank-r child of any node is accepted with probability acc[r]."""
+    succ = growmap["Successors"]
+    reach = [0.0] * len(succ)
+    reach[0] = 1.0
+    for p, kids in enumerate(succ):
+        for r, c in enumerate(kids):
+            reach[c] = reach[p] * (acc[r] if r < len(acc) else 0.0)
+    return sum(reach)

@@ -1,0 +1,371 @@
+"""Host-side logic shared by the static (Sequoia) and dynamic (SpecExec) engines.
+
+Keeps the reference engine surface (umbrella/speculation/base.py:9-59 and the
+public methods of static_speculation_engine.py / dynamic_speculation_engine.py)
+while moving all per-iteration state onto the GPU:
+
+* ``tokens`` (int32), ``num_nodes`` (device scalar) and the tree tables live in
+  HBM; every kernel derives positions / KV slots / mask rows from them, so one
+  whole iteration -- draft levels, top-k expand, verify forward, arg-max, accept
+  scan, KV compaction, state update -- is a single hipGraph replay;
+* the host reads back five ints per iteration (one sync instead of the
+  reference's ``nonzero()`` + ``.tolist()`` pair, static:320,329).
+"""
+from __future__ import annotations
+
+import re
+import time
+
+import torch
+
+from .. import _lib
+from ..logging_config import setup_logger
+from ..models import AutoModelLM
+from ..utils import TextColors
+from .base import BaseEngine
+from .speculation_utils import IdTokenizer, is_sentence_complete_regex
+
+logger = setup_logger()
+
+
+class HipEngine(BaseEngine):
+    MASK_FIRST_EOS = False
+    DRAFT_KW = {}
+    TARGET_KW = {}
+
+    def _common_kwargs(self, kwargs):
+        self.max_length = kwargs.pop("max_length", 8192)
+        self.stop_distance = kwargs.pop("stop_distance", 32)
+        self.safe_buffer = kwargs.pop("safe_buffer", 64)
+        self.temperature = kwargs.pop("temperature", 0.0)
+        self.topp = kwargs.pop("topp", 0.9)
+        self.repetition_penalty = kwargs.pop("repetition_penalty", 1.0)
+        self.topk = kwargs.pop("topk", 32)
+        self.use_graph = kwargs.pop("hip_graph", True)
+        self.seed = kwargs.pop("seed", 0)
+        # optional injected models / tokenizer (tests, synthetic benches)
+        self._draft_model = kwargs.pop("draft_model_obj", None)
+        self._target_model = kwargs.pop("target_model_obj", None)
+        self._tokenizer = kwargs.pop("tokenizer", None)
+        self.token_override = None      # bench knob: fn(engine) called before each iteration (see bench.py)
+
+    # ------------------------------------------------------------------ setup
+    def _load_models(self, draft_kw, target_kw):
+        cfg = dict(self.config)
+        if self._draft_model is None:
+            self.draft_model = AutoModelLM.from_pretrained(model_name=self.draft_model_name, batch_size=1,
+                                                           max_length=self.max_length, device=self.device,
+                                                           dtype=self.dtype, **draft_kw)
+            self.draft_model.alloc(**dict(cfg))
+        else:
+            self.draft_model = self._draft_model
+        if self._target_model is None:
+            self.target_model = AutoModelLM.from_pretrained(model_name=self.target_model_name, batch_size=1,
+                                                            max_length=self.max_length, device=self.device,
+                                                            dtype=self.dtype, **target_kw)
+            self.target_model.alloc(**dict(cfg))
+        else:
+            self.target_model = self._target_model
+        self.max_length = self.target_model.max_length
+        assert self.draft_model.max_length == self.max_length
+        assert self.draft_model.config.vocab_size == self.target_model.config.vocab_size
+        self.vocab_size = self.target_model.config.vocab_size
+        self.eos_tokens = list(self.target_model.eos_tokens)
+        if self._tokenizer is not None:
+            self.tokenizer = self._tokenizer
+        else:
+            try:
+                from transformers import AutoTokenizer
+                self.tokenizer = AutoTokenizer.from_pretrained(self.target_model_name, local_files_only=True)
+            except Exception:
+                self.tokenizer = IdTokenizer()       # no tokenizer files offline: ids <-> "12 7 99" text
+
+    def _alloc_state(self, tree_size, max_path):
+        dev = self.device
+        self.tree_size, self.max_path = tree_size, max_path
+        self.tokens = torch.zeros(self.max_length + tree_size + 8, dtype=torch.int32, device=dev)
+        self.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sampled = torch.zeros(tree_size, dtype=torch.int32, device=dev)
+        self.res = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.res_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.path = torch.zeros(max(max_path, 1), dtype=torch.int32, device=dev)
+        self.eos_dev = torch.tensor(self.eos_tokens or [-1], dtype=torch.int32, device=dev)
+        self.num_nodes = 0
+        self._graph = None
+        self._rng = torch.Generator(device=dev).manual_seed(self.seed)
+        self.draft_model.reserve(max(self.draft_model.CHUNK, self.draft_rows))
+        self.target_model.reserve(max(self.target_model.CHUNK, tree_size))
+
+    # ------------------------------------------------------------------ text API
+    def prefill(self, text: str):
+        input_ids = self.tokenizer.encode(text, return_tensors="pt").to(self.device)
+        return self._prefill(input_ids=input_ids)
+
+    def append(self, text: str):
+        input_ids = self.tokenizer.encode(text, return_tensors="pt").to(self.device)
+        return self._append(input_ids[:, 1:])          # drop the BOS the tokenizer adds (static:140)
+
+    # ------------------------------------------------------------------ prefix handling
+    def _first_token(self, logits_row):
+        if self.MASK_FIRST_EOS and self.eos_tokens:                  # dynamic:130,163
+            _lib.call("umb_mask_eos", logits_row, self.eos_dev, len(self.eos_tokens))
+        first = self.sampled[:1]
+        _lib.call("umb_argmax_rows", first, logits_row, 1, self.vocab_size)
+        return first
+
+    def _feed(self, lo, hi):
+        ids = self.tokens[lo:hi]
+        self.draft_model.prefill_tokens(ids, lo, want_logits=False)
+        row = self.target_model.prefill_tokens(ids, lo, want_logits=True)
+        first = self._first_token(row)
+        self.tokens[hi:hi + 1] = first
+        self.num_nodes = hi
+        self.n_dev.fill_(hi)
+
+    @torch.inference_mode()
+    def _prefill(self, input_ids: torch.LongTensor):
+        P = input_ids.shape[1]
+        if P >= self.max_length - 2 * self.safe_buffer:
+            return False
+        base = self.num_nodes
+        self.tokens[base:base + P] = input_ids[0].to(device=self.device, dtype=torch.int32)
+        self._feed(base, base + P)
+        return True
+
+    @torch.inference_mode()
+    def _append(self, input_ids: torch.LongTensor):
+        A = input_ids.shape[1]
+        if A + self.num_nodes >= self.max_length - 2 * self.safe_buffer:
+            return False
+        n = self.num_nodes
+        self.tokens[n + 1:n + 1 + A] = input_ids[0].to(device=self.device, dtype=torch.int32)
+        self._feed(n, n + A + 1)        # the pending bonus token becomes context (static:183-185)
+        return True
+
+    # ------------------------------------------------------------------ one iteration
+    def _greedy(self):
+        return self.temperature < 0.05 and not (self.repetition_penalty > 1.01)
+
+    def _sample_eager(self):
+        """Non-greedy / penalised path: torch ops on the fp32 logits, then the same accept scan."""
+        T, n = self.tree_size, self.num_nodes
+        logits = self.target_model.logits_buffer[:T]
+        if self.repetition_penalty > 1.01:                            # speculation_utils.py:340-345
+            hist = self.tokens[:n + 1].long()[None].expand(T, -1)
+            g = torch.gather(logits, 1, hist)
+            g = torch.where(g < 0, g * self.repetition_penalty, g / self.repetition_penalty)
+            logits = logits.scatter(1, hist, g)
+        if self.temperature < 0.05:
+            self.sampled.copy_(logits.argmax(dim=-1).int())
+            return
+        k = min(self.topk, logits.size(-1))                           # apply_topk, speculation_utils.py:347-352
+        kth = torch.topk(logits, k)[0][..., -1, None]
+        logits = logits.masked_fill(logits < kth, torch.finfo(logits.dtype).min)
+        p = torch.softmax(logits / self.temperature, dim=-1)
+        sp, si = torch.sort(p, dim=-1, descending=True)               # top-p renormalisation
+        drop = (torch.cumsum(sp, dim=-1) - sp) >= self.topp
+        sp = sp.masked_fill(drop, 0.0)
+        p = torch.zeros_like(p).scatter(-1, si, sp)
+        p = p / p.sum(dim=-1, keepdim=True)
+        self.sampled.copy_(torch.multinomial(p, 1, generator=self._rng).squeeze(-1).int())
+
+    def _commit(self):
+        _lib.call("umb_accept_scan", self.sampled, self.parents, self.tokens, self.n_dev, self.tree_size,
+                  self.eos_dev, len(self.eos_tokens), self.res, self.path)
+        self.draft_model.kv_cache.compact(self.res, self.path, self.max_path)
+        self.target_model.kv_cache.compact(self.res, self.path, self.max_path)
+        self.res_host.copy_(self.res, non_blocking=True)
+
+    def _iteration_launch(self):
+        self.build_tree()
+        self._verify_forward()
+        if self._greedy():
+            _lib.call("umb_argmax_rows", self.sampled, self.target_model.logits_buffer, self.tree_size, self.vocab_size)
+        else:
+            self._sample_eager()
+        self._commit()
+
+    def _capture(self):
+        """Capture one full greedy iteration into a hipGraph (replayed by step())."""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        n_save = self.n_dev.clone()
+        tok_save = self.tokens.clone()
+        with torch.cuda.stream(s):
+            self._iteration_launch()          # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._iteration_launch()
+        torch.cuda.synchronize()
+        self.n_dev.copy_(n_save)
+        self.tokens.copy_(tok_save)
+        self._graph = g
+
+    @torch.inference_mode()
+    def step(self) -> bool:
+        """build_tree + verify as one launch; returns continue_generation."""
+        if self.token_override is not None:
+            self.token_override(self)
+        if self.use_graph and self._greedy() and self.token_override is None:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._iteration_launch()
+        return self._finish_iteration()
+
+    def _finish_iteration(self) -> bool:
+        torch.cuda.current_stream().synchronize()
+        keep, bonus, eos, n_new, raw = self.res_host[:5].tolist()
+        self.last_accept = keep
+        self.num_nodes = n_new
+        self.draft_model.kv_cache.kv_offset = n_new
+        self.target_model.kv_cache.kv_offset = n_new
+        return eos == 0
+
+    @torch.inference_mode()
+    def verify(self):
+        self._verify_forward()
+        if self._greedy():
+            _lib.call("umb_argmax_rows", self.sampled, self.target_model.logits_buffer, self.tree_size, self.vocab_size)
+        else:
+            self._sample_eager()
+        self._commit()
+        return self._finish_iteration()
+
+    # ------------------------------------------------------------------ generation loops
+    def validate_status(self):
+        return self.num_nodes <= (self.max_length - self.safe_buffer)
+
+    def update_generation_args(self, **generation_args):
+        self.temperature = generation_args.pop("temperature", self.temperature)
+        self.topp = generation_args.pop("topp", self.topp)
+        self.repetition_penalty = generation_args.pop("repetition_penalty", self.repetition_penalty)
+        self.topk = generation_args.pop("topk", self.topk)
+
+    @torch.inference_mode()
+    def reset(self):
+        self.num_nodes = 0
+        self.n_dev.zero_()
+        self.tokens.zero_()
+        self.draft_model.clear()
+        self.target_model.clear()
+
+    def _decode_words(self, ids):
+        return (self.tokenizer.decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False,
+                                      spaces_between_special_tokens=False).strip().split(" "))
+
+    def _stop_now(self, words, start, max_new_tokens):
+        done = self.num_nodes - start
+        return (is_sentence_complete_regex(words[-1]) and done >= max_new_tokens - self.stop_distance) or done >= max_new_tokens
+
+    @torch.inference_mode()
+    def speculative_decoding(self, max_new_tokens=128):
+        max_new_tokens = max(max_new_tokens, self.stop_distance)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        steps, decode, start, ids, pos, words = 0, True, self.num_nodes, [], 0, [""]
+        while decode and self.validate_status():
+            begin = self.num_nodes
+            decode = self.step()
+            steps += 1
+            ids.extend(self.tokens[begin:self.num_nodes].tolist())
+            words = self._decode_words(ids)
+            now = len(words) - 1
+            if now > pos:
+                print(" ".join(words[pos:now]), end=" ", flush=True)
+                pos = now
+            if self._stop_now(words, start, max_new_tokens):
+                decode = False
+        print(" ".join(words[pos:]), flush=True)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        dec_len = self.num_nodes - start + 1
+        logger.info(TextColors.colorize("Avg Accept Tokens {:.2f} | TPOT {:.2f} ms ".format(
+            dec_len / max(steps, 1), 1000 * (t2 - t1) / dec_len), "magenta"))
+        return dec_len, (t2 - t1), steps
+
+    def _empty(self, api_args):
+        api_args.update(generated_text="", generated_tokens=[], avg_accept_tokens=0, time_per_output_token=0)
+        return api_args
+
+    def _start_request(self, api_args):
+        self.update_generation_args(**api_args)
+        input_ids = api_args.get("input_ids", None)
+        max_new_tokens = api_args.get("max_new_tokens", 128)
+        if input_ids is None:
+            context = api_args.get("context", None)
+            if context is None or len(context) == 0 or max_new_tokens == 0:
+                return None
+            return self.prefill(context)
+        if len(input_ids) == 0 or max_new_tokens == 0:
+            return None
+        return self._prefill(input_ids=torch.tensor(list(input_ids), dtype=torch.long)[None])
+
+    @torch.inference_mode()
+    def generate(self, **api_args):
+        ok = self._start_request(api_args)
+        if not ok:
+            if ok is False:
+                self.reset()
+            return self._empty(api_args)
+        max_new_tokens = api_args.get("max_new_tokens", 128)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        steps, decode, start = 0, True, self.num_nodes
+        while decode and (self.num_nodes - start) < max_new_tokens and self.validate_status():
+            decode = self.step()
+            steps += 1
+        torch.cuda.synchronize()
+        t2 = time.time()
+        dec_len = self.num_nodes - start + 1
+        toks = self.tokens[start:self.num_nodes + 1].tolist()
+        api_args["generated_text"] = self.tokenizer.decode(toks, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        api_args["generated_tokens"] = toks
+        api_args["avg_accept_tokens"] = dec_len / max(steps, 1)
+        api_args["time_per_output_token"] = 1000 * (t2 - t1) / dec_len
+        self.reset()
+        return api_args
+
+    @torch.inference_mode()
+    def generate_stream(self, **api_args):
+        ok = self._start_request(api_args)
+        if ok is None:
+            self._empty(api_args)
+            return
+        if not ok:
+            yield "Exceeding reserved allowed context length", "Exceeding reserved allowed context length"
+            self.reset()
+            return
+        max_new_tokens = max(api_args.get("max_new_tokens", 128), self.stop_distance)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        steps, decode, start, ids, pos, text, words = 0, True, self.num_nodes, [], 0, "", [""]
+
+        def perf():
+            d = self.num_nodes - start + 1
+            return "Output Tokens {} | Avg Accept Tokens {:.2f} | TPOT {:.2f} ms ".format(
+                d, d / max(steps, 1), 1000 * (time.time() - t1) / d)
+
+        while decode and self.validate_status():
+            begin = self.num_nodes
+            decode = self.step()
+            steps += 1
+            ids.extend(self.tokens[begin:self.num_nodes].tolist())
+            words = self._decode_words(ids)
+            now = len(words) - 1
+            if now > pos:
+                text += " ".join(words[pos:now]) + " "
+                yield text, perf()
+                pos = now
+            if self._stop_now(words, start, max_new_tokens):
+                decode = False
+        tail = " ".join(words[pos:])
+        if tail:
+            text += tail
+        yield text, perf()
+        torch.cuda.synchronize()
+        logger.info(TextColors.colorize(perf(), "magenta"))
+        self.reset()

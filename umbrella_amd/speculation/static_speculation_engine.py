@@ -1,0 +1,92 @@
+"""Static (Sequoia growmap) speculation engine on the HIP path.
+
+Same constructor / methods as the reference class
+(umbrella/speculation/static_speculation_engine.py:21-566).  Differences by
+design: the growmap becomes device tables (depth, parents, bit-packed ancestor
+mask, per-level child placement) instead of a dense [Lmax, 2*Lmax] bool mask;
+the draft levels, top-k child placement, verify forward, arg-max, accept scan
+and KV compaction of one iteration replay as a single hipGraph.
+"""
+from __future__ import annotations
+
+import json
+
+import torch
+
+from .. import _lib
+from ..models.llama import pack_mask_bits
+from .engine_common import HipEngine, logger
+from ..utils import TextColors
+
+
+class StaticSpeculationEngine(HipEngine):
+    MASK_FIRST_EOS = False                      # static:173 plain argmax of the last logit
+
+    def __init__(self, draft_model_name: str, target_model_name: str, dtype=torch.float16, device: str = "cuda:0",
+                 **kwargs) -> None:
+        super().__init__()
+        self.draft_model_name, self.target_model_name = draft_model_name, target_model_name
+        self.dtype, self.device = dtype, device
+        self.growmap_path = kwargs.pop("growmap_path", None)
+        self.growmap = kwargs.pop("growmap", None)
+        assert self.growmap_path is not None or self.growmap is not None, "Please specify growmap path for static trees"
+        self._common_kwargs(kwargs)
+        self.config = kwargs
+
+    def initialize(self):
+        if self.growmap is None:
+            with open(self.growmap_path, "r") as f:
+                self.growmap = json.load(f)
+        gm, dev = self.growmap, self.device
+        T = gm["size"]
+        levels = gm["roots"]
+        self.tree_depth = len(levels)
+        self.branch_lists = gm["branches"]
+        logger.info(TextColors.colorize("Tree Size {} | Tree Depth {}".format(T - 1, self.tree_depth - 1), "magenta"))
+        parents = [0] * T
+        for v, succ in enumerate(gm["Successors"]):
+            for c in succ:
+                parents[c] = v
+        self.parents = torch.tensor(parents, dtype=torch.int32, device=dev)
+        self.depth = torch.tensor(gm["depth"], dtype=torch.int32, device=dev)
+        self.tree_mask = (torch.tensor(gm["mask"]) == 1).to(dev)
+        self.mask_bits = pack_mask_bits(self.tree_mask).contiguous()
+        self.mask_words = self.mask_bits.shape[1]
+        # per-level child placement: children of level i are laid out by (parent order, rank) (static:115-123)
+        self.levels = []
+        for i, ids in enumerate(levels):
+            assert ids == list(range(ids[0], ids[0] + len(ids))), "growmap levels must be contiguous tree offsets"
+            w, k = len(ids), (max(self.branch_lists[i]) if i < self.tree_depth - 1 else 0)
+            starts, cur = [], (levels[i + 1][0] if i + 1 < self.tree_depth else 0)
+            for j in range(w):
+                b = self.branch_lists[i][j] if i < self.tree_depth - 1 else 0
+                assert gm["Successors"][ids[j]] == list(range(cur, cur + b)), "Successors must match branches order"
+                starts.append(cur)
+                cur += b
+            self.levels.append(dict(off=ids[0], w=w, k=k,
+                                    child_start=torch.tensor(starts, dtype=torch.int32, device=dev),
+                                    child_cnt=torch.tensor(self.branch_lists[i] if k else [0] * w, dtype=torch.int32, device=dev)))
+        self.draft_rows = max(l["w"] for l in self.levels)
+        self._load_models(dict(offload=False, cuda_graph=True), dict(offload=False))
+        self._alloc_state(T, self.tree_depth)
+        self.override_tbl = torch.full((T,), -1, dtype=torch.int32, device=dev)
+        self.enable_override = False
+
+    @torch.inference_mode()
+    def build_tree(self):
+        d = self.draft_model
+        for lv in self.levels:
+            has_head = lv["k"] > 0
+            d.forward_tree(self.tokens, self.n_dev, self.depth, lv["off"], lv["w"], self.mask_bits, self.mask_words,
+                           head_from=0 if has_head else lv["w"])
+            if has_head:
+                _lib.call("umb_topk_rows", None, None, d.logits_buffer, lv["w"], self.vocab_size, lv["k"],
+                          self.tokens, self.n_dev, lv["child_start"], lv["child_cnt"])
+                if self.enable_override:
+                    nxt = lv["off"] + lv["w"]
+                    cnt = int(sum(self.branch_lists[self.levels.index(lv)]))
+                    _lib.call("umb_apply_override", self.tokens, self.n_dev, self.override_tbl, nxt, cnt)
+
+    def _verify_forward(self):
+        self.target_model.forward_tree(self.tokens, self.n_dev, self.depth, 0, self.tree_size, self.mask_bits,
+                                       self.mask_words, head_from=0)
