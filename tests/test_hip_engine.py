@@ -158,11 +158,11 @@ def test_dynamic_wide_tree_and_offload(dev):
     """T = 16*6+1 = 97 tokens per verify (token chunks > 64 in the GEMM) and the layer-streaming target."""
     from hip_helpers import check_greedy, dynamic_engine
     dtype = torch.bfloat16
-    eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=12, depth=6, offload=False)
+    eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=16, depth=6, offload=False)
     ref = eng.generate(input_ids=PROMPT, max_new_tokens=40)
     check_greedy(G, sd, PROMPT, ref["generated_tokens"], dtype, mask_first_eos=eng.eos_tokens)
     for ncache in (0, 2):
-        eng2, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=12, depth=6, offload=True,
+        eng2, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=16, num_beams=16, depth=6, offload=True,
                                  num_cache_layers=ncache)
         assert eng2.target_model._off is not None
         out = eng2.generate(input_ids=PROMPT, max_new_tokens=40)

@@ -47,7 +47,6 @@ class HipEngine(BaseEngine):
         self._draft_model = kwargs.pop("draft_model_obj", None)
         self._target_model = kwargs.pop("target_model_obj", None)
         self._tokenizer = kwargs.pop("tokenizer", None)
-        self.token_override = None      # bench knob: fn(engine) called before each iteration (see bench.py)
 
     # ------------------------------------------------------------------ setup
     def _load_models(self, draft_kw, target_kw):
@@ -121,6 +120,7 @@ class HipEngine(BaseEngine):
         self.tokens[hi:hi + 1] = first
         self.num_nodes = hi
         self.n_dev.fill_(hi)
+        self.last_bonus = None
 
     @torch.inference_mode()
     def _prefill(self, input_ids: torch.LongTensor):
@@ -206,9 +206,9 @@ class HipEngine(BaseEngine):
     @torch.inference_mode()
     def step(self) -> bool:
         """build_tree + verify as one launch; returns continue_generation."""
-        if self.token_override is not None:
-            self.token_override(self)
-        if self.use_graph and self._greedy() and self.token_override is None:
+        if getattr(self, "enable_override", False):
+            self._fill_override()
+        if self.use_graph and self._greedy():
             if self._graph is None:
                 self._capture()
             self._graph.replay()
@@ -219,7 +219,7 @@ class HipEngine(BaseEngine):
     def _finish_iteration(self) -> bool:
         torch.cuda.current_stream().synchronize()
         keep, bonus, eos, n_new, raw = self.res_host[:5].tolist()
-        self.last_accept = keep
+        self.last_accept, self.last_bonus = keep, bonus
         self.num_nodes = n_new
         self.draft_model.kv_cache.kv_offset = n_new
         self.target_model.kv_cache.kv_offset = n_new

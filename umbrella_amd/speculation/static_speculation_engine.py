@@ -70,7 +70,48 @@ class StaticSpeculationEngine(HipEngine):
         self._load_models(dict(offload=False, cuda_graph=True), dict(offload=False))
         self._alloc_state(T, self.tree_depth)
         self.override_tbl = torch.full((T,), -1, dtype=torch.int32, device=dev)
+        self.override_host = torch.full((T,), -1, dtype=torch.int32).pin_memory()
         self.enable_override = False
+        self._succ = gm["Successors"]
+
+    # ---- measurement knob (bench.py): controllable-acceptance draft for synthetic weights ----------
+    def set_oracle_draft(self, truth, truth_start: int, acc, seed: int = 0):
+        """Random-weight draft/target pairs accept ~0 drafted tokens, so benchmarks on synthetic
+        checkpoints steer acceptance explicitly: `truth` is the target's own greedy continuation
+        (truth[i] is the token at absolute position truth_start + i).  Before each iteration the host
+        marks, for every depth d, the rank-r child of the on-path node (r ~ Categorical(acc), seeded by
+        the absolute position) to carry the true token; the device applies the table right after each
+        level's top-k.  All draft/verify work still runs; only token ids of <= depth slots change.
+        Must be called before the first step() (the override kernels are part of the captured graph)."""
+        import numpy as np
+        self._truth, self._truth_start = list(truth), truth_start
+        p = np.asarray(list(acc) + [max(0.0, 1.0 - float(sum(acc)))], dtype=np.float64)
+        self._acc_p, self._acc_seed = p / p.sum(), seed
+        self.enable_override = True
+        self._graph = None
+        self.diverged = 0
+
+    def _fill_override(self):
+        import numpy as np
+        tbl = self.override_host
+        tbl.fill_(-1)
+        i0 = self.num_nodes - self._truth_start
+        if getattr(self, "last_bonus", None) is None:
+            self.last_bonus = int(self.tokens[self.num_nodes])
+        if 0 <= i0 < len(self._truth) and self.last_bonus != self._truth[i0]:
+            self.diverged += 1                     # target left the recorded continuation (16-bit near-tie)
+        node = 0
+        for d in range(1, self.tree_depth):
+            if i0 + d >= len(self._truth) or i0 < 0:
+                break
+            rs = np.random.RandomState((self._acc_seed * 1000003 + self.num_nodes + d) % (2**31 - 1))
+            r = int(rs.choice(len(self._acc_p), p=self._acc_p))
+            kids = self._succ[node]
+            if r >= len(kids):
+                break
+            node = kids[r]
+            tbl[node] = self._truth[i0 + d]
+        self.override_tbl.copy_(tbl, non_blocking=True)
 
     @torch.inference_mode()
     def build_tree(self):
