@@ -225,6 +225,25 @@ def main():
     raw_tps = raw_tokens / raw_dt
     raw_accept = raw_tokens / max(raw_steps, 1)
 
+    # A token verified as a depth-d tree node sums its attention in a different order than the same token
+    # verified as a root, so on random-init weights a 16-bit near-tie can flip the target's arg-max about
+    # once per ~50 tokens and leave the recorded continuation.  The kernels are deterministic, so the
+    # continuation is re-recorded under the knob's own execution pattern until it is a fixed point
+    # (each pass reproduces the previous one bit-for-bit up to its first divergence).
+    passes = 0
+    for passes in range(1, 9):
+        eng.reset()
+        assert eng._prefill(prompt)
+        eng.set_oracle_draft(truth, start, acc, seed=args.seed)
+        run_steps(eng, args.warmup + args.steps)
+        div = eng.diverged
+        while eng.num_nodes - start < need and eng.validate_status():
+            eng.step()
+        new_truth = eng.tokens[start:eng.num_nodes + 1].tolist()
+        if div == 0:
+            break
+        truth = new_truth
+
     # ---- timed: acceptance knob on
     eng.reset()
     assert eng._prefill(prompt)
@@ -269,7 +288,7 @@ def main():
                           "prompt_len": args.prompt_len, "max_length": args.max_length, "acc": acc,
                           "parallelism": "1 engine per GPU (replicas)" if world > 1 else "single GPU"},
                "accept_len": round(accept_len, 3), "value_raw_draft": round(raw_tps, 2),
-               "accept_len_raw_draft": round(raw_accept, 3), "oracle_draft_divergence": getattr(eng, "diverged", 0),
+               "accept_len_raw_draft": round(raw_accept, 3), "oracle_draft_divergence": getattr(eng, "diverged", 0), "oracle_draft_passes": passes,
                "iter_bytes_GB": round(bytes_iter / 1e9, 3),
                "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_roofline:

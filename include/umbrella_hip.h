@@ -27,13 +27,14 @@ typedef struct ihipStream_t* umb_stream_t;   /* == hipStream_t */
 
 /* ------------------------------------------------------------------ weights (load time) */
 /* dense W[N][K] row-major (HF layout; umbrella/models/llama_layer.py:25-40) -> MFMA tile order.
- * out: N*K 16-bit elements. */
-int umb_repack_dense(void* out, const void* w, int N, int K, int dtype, umb_stream_t stream);
+ * out: N*K 16-bit elements.  interleave != 0: packed rows (2m, 2m+1) <- source rows (m, N/2 + m), i.e. a fused
+ * [gate; up] weight is stored as (gate_m, up_m) pairs so SiLU(gate)*up can be the GEMM epilogue. */
+int umb_repack_dense(void* out, const void* w, int N, int K, int interleave, int dtype, umb_stream_t stream);
 /* AutoAWQ GEMM tensors (umbrella/quantization/awq_utils.py:20-27: qweight [K][N/8] i32,
  * qzeros [K/128][N/8] i32, scales [K/128][N] fp16) -> int4 tile order.
  * outw: N*K/2 bytes, meta: (N/16)*(K/128)*48 bytes (16 fp16 scales + 16 u8 zeros per tile). */
 int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
-                   int N, int K, int group, umb_stream_t stream);
+                   int N, int K, int group, int interleave, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ linear layers */
 /* split plan for a [N][K] linear: depends on (N, K, format) only, never on T. */
@@ -41,10 +42,11 @@ void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out);
 /* out[S][T][N] (fp32 split-K partials) = x[T][K] (row stride ldx) . W^T
  * replaces F.linear (umbrella/models/llama.py:89-91,103,107-111,133) and
  * AwqLinear.apply -> awq_ext.gemm_forward_cuda / dequantize_weights_cuda
- * (umbrella/quantization/awq_utils.py:63-86).  round_out: round results to `dtype`
- * (what F.linear(...).float() yields for the lm_head, llama.py:133). */
+ * (umbrella/quantization/awq_utils.py:63-86).  epi: 0 raw fp32 partials; 1 round results to `dtype`
+ * (what F.linear(...).float() yields for the lm_head, llama.py:133); 2 fused SiLU(gate)*up
+ * (llama.py:107-110): needs S == 1 and interleaved rows, `out` is then 16-bit act[T][N/2]. */
 int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
-             int awq, int S, int R, int round_out, int dtype, umb_stream_t stream);
+             int awq, int S, int R, int epi, int dtype, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ fused epilogues */
 /* flashinfer.rmsnorm (umbrella/models/model_utils.py:54-64) */
@@ -173,6 +175,9 @@ typedef struct UmbOffload {
 } UmbOffload;
 int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbOffload* off,
                               umb_stream_t stream);
+
+/* diagnostic: n dependent no-op launches of `blocks` workgroups (dispatch cadence) */
+int umb_bench_launch(int n, int blocks, int* p, umb_stream_t stream);
 
 const char* umb_version(void);
 

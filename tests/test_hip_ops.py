@@ -291,3 +291,32 @@ def test_kv_compaction(dev, D):
     c2.k.copy_(k0); c2.vt.copy_(v0)
     c2.gather_kv_incremental(idx, n_old)
     assert torch.equal(c2.k, ke) and torch.equal(c2.vt, ve) and c2.kv_offset == n_old + 4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("awq", [False, True])
+@pytest.mark.parametrize("T", [1, 13, 40])
+def test_gemm_fused_silu_epilogue(dev, dtype, awq, T):
+    """[gate; up] stored as interleaved rows: SiLU(gate)*up is the GEMM epilogue (umbrella/models/llama.py:107-110)."""
+    from umbrella_amd.models.awq_format import pack_rows
+    from umbrella_amd.models.llama import PackedLinear
+    rs = np.random.RandomState(T + int(awq))
+    I, K = 768, 512
+    x = torch.from_numpy(rs.randn(T, K).astype(np.float32)).to(dtype)
+    if awq:
+        q = rs.randint(0, 16, size=(K, 2 * I)).astype(np.uint8)
+        z = rs.randint(0, 16, size=(K // 128, 2 * I)).astype(np.uint8)
+        s = (rs.rand(K // 128, 2 * I) * 0.02 + 0.002).astype(np.float16)
+        W = torch.from_numpy((q.astype(np.float32) - np.repeat(z, 128, 0)) * np.repeat(s.astype(np.float32), 128, 0)).t()
+        lin = PackedLinear.from_awq(torch.from_numpy(pack_rows(q)).to(dev), torch.from_numpy(pack_rows(z)).to(dev),
+                                    torch.from_numpy(s).to(dev), interleave=True)
+    else:
+        W = (torch.from_numpy(rs.randn(2 * I, K).astype(np.float32)) * 0.05).to(dtype).float()
+        lin = PackedLinear.from_dense(W.to(dtype).to(dev), interleave=True)
+    assert lin.S == 1
+    act = lin.apply_silu(x.to(dev)).cpu()
+    full = x.float() @ W.t()
+    gate, up = full[:, :I].to(dtype), full[:, I:].to(dtype)
+    ref = torch.nn.functional.silu(gate) * up
+    assert act.shape == (T, I)
+    assert (act.float() - ref.float()).abs().max() <= 8 * torch.finfo(dtype).eps * ref.float().abs().max()

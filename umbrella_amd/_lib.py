@@ -66,8 +66,8 @@ class UmbOffload(C.Structure):
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes (all return int unless listed in _VOID / _STR)
 SIGNATURES = {
-    "umb_repack_dense": [_P, _P, _I, _I, _I, _P],
-    "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "umb_repack_dense": [_P, _P, _I, _I, _I, _I, _P],
+    "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "umb_gemm_plan": [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)],
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],
@@ -88,6 +88,7 @@ SIGNATURES = {
     "umb_model_forward": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), _P],
     "umb_model_forward_offload": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep),
                                   C.POINTER(UmbOffload), _P],
+    "umb_bench_launch": [_I, _I, _P, _P],
     "umb_version": [],
 }
 _VOID = {"umb_gemm_plan"}

@@ -61,19 +61,29 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
-      // ---- S^T: two 16-key subtiles; row i of subtile s <-> key k0 + (i>>2)*8 + s*4 + (i&3)
-      f32x4 st[2];
+    // K fragments of one 32-key tile: two 16-key subtiles; row i of subtile s <-> key k0 + (i>>2)*8 + s*4 + (i&3)
+    auto load_k = [&](int k0, u32x4 (&ak)[2][DS]) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int key = k0 + (j >> 2) * 8 + s * 4 + (j & 3);
         const u16* kp = kbase + (long)key * D + gq * 8;
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds)
+          ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
+      }
+    };
+    auto tile = [&](int k0, const u32x4 (&ak)[2][DS]) {
+      // A = V^T tiles: lane (i = j -> d row, gq) holds keys k0 + gq*8 .. +7 (16 B, 8-key aligned); issued first
+      u32x4 av[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * Lmax + k0 + gq * 8);
+      f32x4 st[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) {
-          const u32x4 ak = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
-          acc = P::mfma(ak, bq[ds], acc);
-        }
+        for (int ds = 0; ds < DS; ++ds) acc = P::mfma(ak[s][ds], bq[ds], acc);
         st[s] = acc;
       }
       // lane (j, gq) now holds scores of query row `row` vs keys k0 + gq*8 + s*4 + r
@@ -109,10 +119,20 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
       m = m_new;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        // A = V^T tile: lane (i = j -> d row, gq) holds keys k0 + gq*8 .. +7 (16 B, 8-key aligned)
-        const u32x4 av = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * Lmax + k0 + gq * 8);
         o[dt] *= alpha;
-        o[dt] = P::mfma(av, pb, o[dt]);
+        o[dt] = P::mfma(av[dt], pb, o[dt]);
+      }
+    };
+
+    u32x4 ka[2][DS], kb2[2][DS];
+    load_k(k_lo, ka);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+      const bool two = k0 + 32 < k_hi;
+      if (two) load_k(k0 + 32, kb2);
+      tile(k0, ka);
+      if (two) {
+        if (k0 + 64 < k_hi) load_k(k0 + 64, ka);
+        tile(k0 + 32, kb2);
       }
     }
     l += __shfl_xor(l, 16, 64);

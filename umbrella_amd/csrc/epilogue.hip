@@ -35,24 +35,36 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(u16* __restrict__ out, con
   }
 }
 
-// ---- h = residual + sum_s partial ; xn = rmsnorm(h) * w   (one block per token row)
+// ---- h = residual + sum_s partial ; xn = rmsnorm(h) * w   (one 1024-thread block per token row)
 // h_out may alias residual.  xn_out / w may be null (no norm), residual may be null.
+// The split loop is unrolled 4-wide so the partial loads are independent (latency, not bandwidth, bound).
+__device__ __forceinline__ f32x4 sum_splits(const float* __restrict__ p, int S, long sstride) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  int s = 1;
+  for (; s + 3 < S; s += 4) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p + (long)s * sstride);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p + (long)(s + 1) * sstride);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p + (long)(s + 2) * sstride);
+    const f32x4 b3 = *reinterpret_cast<const f32x4*>(p + (long)(s + 3) * sstride);
+    a += b0; a += b1; a += b2; a += b3;          // fixed order 0..S-1
+  }
+  for (; s < S; ++s) a += *reinterpret_cast<const f32x4*>(p + (long)s * sstride);
+  return a;
+}
+
 template <typename P>
-__global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* __restrict__ part, int S, int T, int N,
-                                                                   const u16* residual, u16* h_out,
-                                                                   u16* __restrict__ xn_out,
-                                                                   const u16* __restrict__ w, float eps) {
+__global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float* __restrict__ part, int S, int T, int N,
+                                                                    const u16* residual, u16* h_out,
+                                                                    u16* __restrict__ xn_out,
+                                                                    const u16* __restrict__ w, float eps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);            // 4 floats
-  u16* row = reinterpret_cast<u16*>(smem + 16);           // N x u16
+  float* red = reinterpret_cast<float*>(smem);            // 16 floats
+  u16* row = reinterpret_cast<u16*>(smem + 64);           // N x u16
   const int t = blockIdx.x;
+  const long sstride = (long)T * N;
   float ss = 0.f;
-  for (int i = threadIdx.x * 4; i < N; i += 256 * 4) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(part + (long)t * N + i);
-    for (int s = 1; s < S; ++s) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(part + ((long)s * T + t) * N + i);
-      a += b;
-    }
+  for (int i = threadIdx.x * 4; i < N; i += 1024 * 4) {
+    const f32x4 a = sum_splits(part + (long)t * N + i, S, sstride);
     // GEMM output is rounded to the model dtype before the residual add (F.linear returns dtype)
     float v0 = rnd<P>(a[0]), v1 = rnd<P>(a[1]), v2 = rnd<P>(a[2]), v3 = rnd<P>(a[3]);
     if (residual) {
@@ -67,9 +79,9 @@ __global__ __launch_bounds__(256) void reduce_residual_norm_kernel(const float* 
     ss += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
   }
   if (!xn_out) return;
-  ss = block_sum<256>(ss, red);
+  ss = block_sum<1024>(ss, red);
   const float inv = rsqrtf(ss / (float)N + eps);
-  for (int i = threadIdx.x * 4; i < N; i += 256 * 4) {
+  for (int i = threadIdx.x * 4; i < N; i += 1024 * 4) {
     const uint2 v = *reinterpret_cast<const uint2*>(row + i);
     const uint2 g = *reinterpret_cast<const uint2*>(w + i);
     uint2 o;
@@ -186,9 +198,9 @@ extern "C" int umb_rmsnorm(void* out, const void* x, const void* w, float eps, i
 extern "C" int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
                                         void* xn_out, const void* w, float eps, int dtype, hipStream_t st) {
   if (N % 4 || T < 1) return UMB_EINVAL;
-  const size_t sm = 16 + (size_t)N * 2;
+  const size_t sm = 64 + (size_t)N * 2;
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((reduce_residual_norm_kernel<P>), dim3(T), dim3(256), sm, st, (const float*)partial, S, T, N,
+    hipLaunchKernelGGL((reduce_residual_norm_kernel<P>), dim3(T), dim3(1024), sm, st, (const float*)partial, S, T, N,
                        (const u16*)residual, (u16*)h_out, (u16*)xn_out, (const u16*)w, eps);
   })
   UMB_LAUNCH_CHECK();

@@ -25,7 +25,7 @@
 
 // ------------------------------------------------------------------ repack (load time)
 template <typename P>
-__global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict__ out, int N, int K) {
+__global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict__ out, int N, int K, int il) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int KT = K / 32;
   const long total = (long)(N / 16) * KT * 64;
@@ -34,14 +34,16 @@ __global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict
   const long tile = gid >> 6;
   const int kt = tile % KT, nt = tile / KT;
   const int i = lane & 15, g = lane >> 4;
-  out[gid] = *reinterpret_cast<const u32x4*>(W + (long)(nt * 16 + i) * K + kt * 32 + g * 8);
+  const int n = nt * 16 + i;
+  const int src = il ? ((n & 1) ? N / 2 + (n >> 1) : (n >> 1)) : n;   // il: rows (2m, 2m+1) <- (m, N/2 + m)
+  out[gid] = *reinterpret_cast<const u32x4*>(W + (long)src * K + kt * 32 + g * 8);
 }
 
 // AutoAWQ GEMM format -> tile order.  qweight [K][N/8] int32, nibble idx of word c
 // holds column 8c + ORDER[idx], ORDER = {0,2,4,6,1,3,5,7}  (inverse: INV below).
 __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const unsigned* __restrict__ qzeros,
                                   const u16* __restrict__ scales, u32x4* __restrict__ outw,
-                                  unsigned char* __restrict__ meta, int N, int K) {
+                                  unsigned char* __restrict__ meta, int N, int K, int il) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int KG = K / 128;
   const long total = (long)(N / 16) * KG * 64;
@@ -50,7 +52,8 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
   const long tile = gid >> 6;
   const int kg = tile % KG, nt = tile / KG;
   const int i = lane & 15, g = lane >> 4;
-  const int n = nt * 16 + i;
+  const int nlog = nt * 16 + i;
+  const int n = il ? ((nlog & 1) ? N / 2 + (nlog >> 1) : (nlog >> 1)) : nlog;   // source column
   const int INV[8] = {0, 4, 1, 5, 2, 6, 3, 7};
   const int sh = 4 * INV[n & 7];
   const int NW = N / 8;
@@ -76,46 +79,47 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
 }
 
 // ------------------------------------------------------------------ main kernel
-template <typename P, int AWQ, int TT, int R> struct Stage {
+// Block = 4 waves on the same K-slab; wave w owns n-tiles [(4*nb + w)*R, +R).  The activation
+// fragments of a CB x 128-k chunk are staged ONCE per block in LDS in fragment (lane-linear) order
+// -> conflict-free ds_read_b128, 4x less L2->L1 traffic than per-wave loads (the int4 path reads
+// 4 KiB of activations per 1 KiB weight tile, so unshared B loads were the bottleneck).
+// Weight tiles go straight from HBM to VGPRs (non-temporal), double buffered across 128-k blocks.
+template <typename P, int AWQ, int R> struct Stage {
   u32x4 a[R][AWQ ? 1 : 4];
-  u32x4 b[TT][4];
   uint2 sc[AWQ ? R : 1];
   unsigned zz[AWQ ? R : 1];
 };
 
-template <typename P, int AWQ, int TT, int R>
-__device__ __forceinline__ void stage_load(Stage<P, AWQ, TT, R>& st, const u32x4* __restrict__ wp,
-                                           const unsigned char* __restrict__ meta, const u16* __restrict__ x,
-                                           int ldx, int T, int nt0, int KU, int kb, int lane) {
-  const int j = lane & 15, g = lane >> 4;
+template <typename P, int AWQ, int R>
+__device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const u32x4* __restrict__ wp,
+                                           const unsigned char* __restrict__ meta, int nt0, int KB, int kb,
+                                           int lane) {
+  const int g = lane >> 4;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (AWQ) {
-      const long tile = (long)(nt0 + r) * KU + kb;
+      const long tile = (long)(nt0 + r) * KB + kb;
       st.a[r][0] = __builtin_nontemporal_load(wp + tile * 64 + lane);
       const unsigned char* m = meta + tile * 48;
       st.sc[r] = *reinterpret_cast<const uint2*>(m + g * 8);
       st.zz[r] = *reinterpret_cast<const unsigned*>(m + 32 + g * 4);
     } else {
-      const u32x4* p = wp + ((long)(nt0 + r) * KU + kb) * 256 + lane;   // 4 tiles (128 k) contiguous
+      const u32x4* p = wp + ((long)(nt0 + r) * KB + kb) * 256 + lane;   // 4 tiles (128 k) contiguous
 #pragma unroll
       for (int s = 0; s < 4; ++s) st.a[r][s] = __builtin_nontemporal_load(p + s * 64);
     }
   }
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int tok = tt * 16 + j;
-    const u16* xp = x + (long)tok * ldx + kb * 128 + g * 8;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      st.b[tt][s] = (tok < T) ? *reinterpret_cast<const u32x4*>(xp + s * 32) : z;
-    }
-  }
 }
 
+// xf: LDS fragments of this 128-k block, index (tt*4 + s)*64 + lane
 template <typename P, int AWQ, int TT, int R>
-__device__ __forceinline__ void stage_compute(const Stage<P, AWQ, TT, R>& st, f32x4 (&acc)[R][TT]) {
+__device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const u32x4* xf, int lane,
+                                              f32x4 (&acc)[R][TT]) {
+  u32x4 b[TT][4];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
   if (AWQ) {
     const u32x4 ones = {P::ONE2, P::ONE2, P::ONE2, P::ONE2};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -124,7 +128,7 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, TT, R>& st, f3
     for (int tt = 0; tt < TT; ++tt) {
       xs[tt] = zero;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xs[tt] = P::mfma(ones, st.b[tt][s], xs[tt]);
+      for (int s = 0; s < 4; ++s) xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, TT, R>& st, f3
         f[2] = ((w >> 8) & 0x000F000Fu) | P::MAGIC;
         f[3] = ((w >> 12) & 0x000F000Fu) | P::MAGIC;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) ga[tt] = P::mfma(f, st.b[tt][s], ga[tt]);
+        for (int tt = 0; tt < TT; ++tt) ga[tt] = P::mfma(f, b[tt][s], ga[tt]);
       }
       const float s0 = F16::to_f((u16)(st.sc[r].x & 0xffffu)), s1 = F16::to_f((u16)(st.sc[r].x >> 16));
       const float s2 = F16::to_f((u16)(st.sc[r].y & 0xffffu)), s3 = F16::to_f((u16)(st.sc[r].y >> 16));
@@ -162,29 +166,35 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, TT, R>& st, f3
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[r][tt] = P::mfma(st.a[r][s], st.b[tt][s], acc[r][tt]);
+        for (int tt = 0; tt < TT; ++tt) acc[r][tt] = P::mfma(st.a[r][s], b[tt][s], acc[r][tt]);
   }
 }
 
-template <typename P, int AWQ, int TT, int R>
+enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2 };
+
+template <typename P, int AWQ, int TT, int R, int CB>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
                                                           const unsigned char* __restrict__ meta,
                                                           const u16* __restrict__ x, int ldx,
                                                           float* __restrict__ out, int T, int Ttot, int N, int K,
-                                                          int S, int round_out) {
+                                                          int S, int epi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);
+  constexpr int F = CB * TT * 4;           // 1 KiB fragments per chunk
+  constexpr int FPW = F / 4;               // fragments staged per wave
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
   const int NT = N / 16;
-  const int ngroups = NT / R;
-  const long task = (long)blockIdx.x * 4 + wv;
-  if (task >= (long)ngroups * S) return;
-  const int sp = (int)(task / ngroups);
-  const int nt0 = (int)(task % ngroups) * R;
-  const int KB = K / 128;                                  // 128-k blocks
-  const int KU = AWQ ? KB : KB;                            // tile stride unit is the 128-k block in both formats
+  const int nblk = (NT + 4 * R - 1) / (4 * R);
+  const int sp = blockIdx.x / nblk;
+  const int nt0 = ((blockIdx.x % nblk) * 4 + wv) * R;
+  const bool active = nt0 < NT;            // NT % R == 0 (host guarantees)
+  const int KB = K / 128;
   const int per = (KB + S - 1) / S;
   const int kb0 = sp * per;
   const int kb1 = min(KB, kb0 + per);
+  const int nchunks = (kb1 - kb0 + CB - 1) / CB;
 
   f32x4 acc[R][TT];
 #pragma unroll
@@ -192,18 +202,48 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[r][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  Stage<P, AWQ, TT, R> s0, s1;
-  if (kb0 < kb1) stage_load<P, AWQ, TT, R>(s0, wp, meta, x, ldx, T, nt0, KU, kb0, lane);
-  int kb = kb0;
-  for (; kb + 1 < kb1; kb += 2) {
-    stage_load<P, AWQ, TT, R>(s1, wp, meta, x, ldx, T, nt0, KU, kb + 1, lane);
-    stage_compute<P, AWQ, TT, R>(s0, acc);
-    if (kb + 2 < kb1) stage_load<P, AWQ, TT, R>(s0, wp, meta, x, ldx, T, nt0, KU, kb + 2, lane);
-    stage_compute<P, AWQ, TT, R>(s1, acc);
-  }
-  if (kb < kb1) stage_compute<P, AWQ, TT, R>(s0, acc);
+  u32x4 xr[FPW];
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      const int f = i * 4 + wv;
+      const int kb = kb0 + c * CB + f / (TT * 4);
+      const int tok = ((f >> 2) % TT) * 16 + j;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      xr[i] = (tok < T && kb < kb1)
+                  ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + kb * 128 + (f & 3) * 32 + g * 8) : z;
+    }
+  };
+  auto store_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
+  };
 
-  const int j = lane & 15, g = lane >> 4;
+  Stage<P, AWQ, R> s0, s1;
+  load_x(0);
+  if (active && kb0 < kb1) stage_load<P, AWQ, R>(s0, wp, meta, nt0, KB, kb0, lane);
+  for (int c = 0; c < nchunks; ++c) {
+    store_x(c);
+    __syncthreads();
+    if (c + 1 < nchunks) load_x(c + 1);
+    if (active) {
+      const u32x4* xc = xs + (c & 1) * F * 64;
+#pragma unroll
+      for (int kl = 0; kl < CB; kl += 2) {
+        const int kb = kb0 + c * CB + kl;
+        if (kb < kb1) {
+          if (kb + 1 < kb1) stage_load<P, AWQ, R>(s1, wp, meta, nt0, KB, kb + 1, lane);
+          stage_compute<P, AWQ, TT, R>(s0, xc + kl * TT * 4 * 64, lane, acc);
+          if (kb + 1 < kb1) {
+            if (kb + 2 < kb1) stage_load<P, AWQ, R>(s0, wp, meta, nt0, KB, kb + 2, lane);
+            stage_compute<P, AWQ, TT, R>(s1, xc + (kl + 1) * TT * 4 * 64, lane, acc);
+          }
+        }
+      }
+    }
+  }
+  if (!active) return;
+
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int tok = tt * 16 + j;
@@ -211,8 +251,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v = acc[r][tt];
-        if (round_out) { v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
-        *reinterpret_cast<f32x4*>(out + ((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) = v;
+        if (epi == EPI_SILU) {
+          // rows are interleaved (gate_m, up_m): act[tok][m] = silu(gate) * up, every step rounded to the
+          // model dtype as eager torch does (umbrella/models/llama.py:107-110).  out is 16-bit [Ttot][N/2].
+          const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
+          const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
+          u16* act = reinterpret_cast<u16*>(out);
+          *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + (nt0 + r) * 8 + g * 2) = pack2<P>(a0, a1);
+        } else {
+          if (epi == EPI_ROUND) { v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
+          *reinterpret_cast<f32x4*>(out + ((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) = v;
+        }
       }
     }
   }
@@ -224,14 +273,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out) {
   const int NT = N / 16, KB = K / 128;
   int R = 1;
-  const int maxR = awq ? 4 : 2;
-  for (int c = maxR; c > 1; c >>= 1)
-    if (NT % c == 0 && NT / c >= 1024) { R = c; break; }
+  if (NT % 2 == 0 && NT >= 4096) R = 2;
   int S = 1;
   if (!force_s1) {
-    const int groups = NT / R;
-    S = (2048 + groups - 1) / groups;
-    const int min_blocks = awq ? 4 : 2;                     // keep >= 512 / 256 k per slab
+    const int nblk = (NT + 4 * R - 1) / (4 * R);
+    S = (1024 + nblk - 1) / nblk;                            // aim at ~1024 blocks (16 waves / CU)
+    const int min_blocks = awq ? 4 : 2;                       // keep >= 512 / 256 k per slab
     if (S > KB / min_blocks) S = KB / min_blocks;
     if (S > 16) S = 16;
     if (S < 1) S = 1;
@@ -240,58 +287,62 @@ extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, i
   *S_out = S;
 }
 
-template <typename P, int AWQ, int TT>
-static int launch_r(int R, const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot,
-                    int N, int K, int S, int round_out, hipStream_t st) {
-  const long tasks = (long)(N / 16 / R) * S;
-  const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-#define L_(RR)                                                                                          \
-  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, RR>), grid, block, 0, st, (const u32x4*)wp,         \
-                     (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, round_out)
-  if (R == 1) L_(1);
-  else if (R == 2) L_(2);
-  else if (R == 4) {
-    if constexpr (AWQ) L_(4);
-    else return UMB_EINVAL;
-  } else return UMB_EINVAL;
-#undef L_
+template <typename P, int AWQ, int TT, int R, int CB>
+static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot, int N,
+                    int K, int S, int epi, hipStream_t st) {
+  const int NT = N / 16;
+  const int nblk = (NT + 4 * R - 1) / (4 * R);
+  const size_t smem = (size_t)2 * CB * TT * 4 * 1024;
+  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB>), dim3((unsigned)(nblk * S)), dim3(256), smem, st,
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }
 
+template <typename P, int AWQ, int TT, int CB>
+static int launch_r(int R, const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot,
+                    int N, int K, int S, int epi, hipStream_t st) {
+  if ((N / 16) % R) return UMB_EINVAL;
+  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, st);
+  if (R == 2) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, st);
+  return UMB_EINVAL;
+}
+
 template <typename P, int AWQ>
 static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int N, int K, int R,
-                     int S, int round_out, hipStream_t st) {
+                     int S, int epi, hipStream_t st) {
   // tokens beyond 64 go through further launches (weights re-read from L2/HBM)
+  const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
   for (int t0 = 0; t0 < T; t0 += 64) {
     const int tn = min(64, T - t0);
     const u16* xx = x + (long)t0 * ldx;
-    float* oo = out + (long)t0 * N;            // out is [S][T][N] over the full T; split stride stays T
+    float* oo = out + (long)t0 * ostride;      // out is [S][T][N] over the full T; split stride stays T
     int rc;
-    if (tn <= 16) rc = launch_r<P, AWQ, 1>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, round_out, st);
-    else if (tn <= 32) rc = launch_r<P, AWQ, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, round_out, st);
-    else rc = launch_r<P, AWQ, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, round_out, st);
+    if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
+    else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
+    else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
     if (rc) return rc;
   }
   return UMB_OK;
 }
 
-// out: fp32 [S][T][N] partials (S from umb_gemm_plan, or 1 when force_s1)
+// out: fp32 [S][T][N] partials (epi 0/1) or 16-bit act [T][N/2] (epi 2 = fused SiLU*up, needs S == 1 and
+// gate/up rows interleaved by the repack, see umb_repack_* `interleave`)
 extern "C" int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
-                        int awq, int S, int R, int round_out, int dtype, hipStream_t st) {
-  if (N % 16 || K % 128 || T < 1 || S < 1) return UMB_EINVAL;
+                        int awq, int S, int R, int epi, int dtype, hipStream_t st) {
+  if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 2 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
   DISPATCH_DTYPE(dtype, {
-    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, round_out, st);
-    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, round_out, st);
+    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
+    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
   })
 }
 
-extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int dtype, hipStream_t st) {
+extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int interleave, int dtype, hipStream_t st) {
   if (N % 16 || K % 32) return UMB_EINVAL;
   const long total = (long)(N / 16) * (K / 32) * 64;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((repack_dense_kernel<P>), grid, block, 0, st, (const u16*)w, (u32x4*)out, N, K);
+    hipLaunchKernelGGL((repack_dense_kernel<P>), grid, block, 0, st, (const u16*)w, (u32x4*)out, N, K, interleave);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;
@@ -299,12 +350,12 @@ extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int dtyp
 
 // outw: N*K/2 bytes; meta: (N/16)*(K/128)*48 bytes
 extern "C" int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
-                              int N, int K, int group, hipStream_t st) {
+                              int N, int K, int group, int interleave, hipStream_t st) {
   if (N % 16 || K % 128 || group != 128) return UMB_EINVAL;
   const long total = (long)(N / 16) * (K / 128) * 64;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipLaunchKernelGGL(repack_awq_kernel, grid, block, 0, st, (const unsigned*)qweight, (const unsigned*)qzeros,
-                     (const u16*)scales, (u32x4*)outw, (unsigned char*)meta, N, K);
+                     (const u16*)scales, (u32x4*)outw, (unsigned char*)meta, N, K, interleave);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

@@ -20,8 +20,8 @@ extern "C" int umb_tree_attn(void*, const void*, const void*, const void*, void*
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
 static inline int lin(const UmbLinear& l, const void* x, int ldx, float* out, int T, int dtype, hipStream_t st,
-                      int round_out = 0) {
-  return umb_gemm(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, l.S, l.R, round_out, dtype, st);
+                      int epi = 0) {
+  return umb_gemm(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, l.S, l.R, epi, dtype, st);
 }
 
 static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
@@ -52,8 +52,9 @@ static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, co
                    st));
   CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st));
   CK(umb_reduce_residual_norm(ws->partial, ly.o.S, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
-  CK(lin(ly.gu, ws->xn, m->H, ws->partial, T, dt, st));
-  CK(umb_reduce_silu_mul(ws->partial, ly.gu.S, T, m->I, ws->act, dt, st));
+  // gate/up rows are interleaved at load time and the GEMM runs unsplit: SiLU(gate)*up is its epilogue
+  if (ly.gu.S != 1) return UMB_EINVAL;
+  CK(lin(ly.gu, ws->xn, m->H, (float*)ws->act, T, dt, st, /*epi=*/2));
   CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st));
   CK(umb_reduce_residual_norm(ws->partial, ly.down.S, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
                               m->eps, dt, st));
@@ -64,7 +65,7 @@ static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hip
   if (s->head_from >= s->T) return UMB_OK;
   const int rows = s->T - s->head_from;
   const char* x = (const char*)ws->xn + (size_t)s->head_from * m->H * 2;
-  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*round_out=*/1);
+  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*epi=EPI_ROUND*/1);
 }
 
 extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {

@@ -32,17 +32,41 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
+// per-thread maximum key over a row: 16 independent 4-byte-wide loads in flight per thread (V % 4 == 0 fast path)
+__device__ __forceinline__ unsigned long long scan_row_max(const float* __restrict__ row, int V) {
+  unsigned long long best = 0ull;
+  if ((V & 3) == 0) {
+    const int V4 = V >> 2;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < V4; i += 4 * 1024) {
+      const f32x4 a = r4[i], b = r4[i + 1024], c = r4[i + 2048], d = r4[i + 3072];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned long long k0 = mk_key(a[e], i * 4 + e), k1 = mk_key(b[e], (i + 1024) * 4 + e);
+        unsigned long long k2 = mk_key(c[e], (i + 2048) * 4 + e), k3 = mk_key(d[e], (i + 3072) * 4 + e);
+        k0 = k0 > k1 ? k0 : k1; k2 = k2 > k3 ? k2 : k3; k0 = k0 > k2 ? k0 : k2;
+        best = k0 > best ? k0 : best;
+      }
+    }
+    for (; i < V4; i += 1024) {
+      const f32x4 a = r4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const unsigned long long k = mk_key(a[e], i * 4 + e); best = k > best ? k : best; }
+    }
+  } else {
+    for (int i = threadIdx.x; i < V; i += 1024) { const unsigned long long k = mk_key(row[i], i); best = k > best ? k : best; }
+  }
+  return best;
+}
+
 // ---- row argmax: one block (1024 threads) per row
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, int V,
                                                            int* __restrict__ out) {
   __shared__ unsigned long long red[16];
   const float* row = logits + (long)blockIdx.x * V;
-  unsigned long long best = 0ull;
-  for (int i = threadIdx.x; i < V; i += 1024) {
-    const unsigned long long k = mk_key(row[i], i);
-    best = k > best ? k : best;
-  }
-  best = wave_max_u64(best);
+  const unsigned long long best0 = scan_row_max(row, V);
+  unsigned long long best = wave_max_u64(best0);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
   __syncthreads();
   if (threadIdx.x < 64) {
@@ -81,23 +105,33 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
   __shared__ unsigned long long cand[1024];
   __shared__ int ncand;
   const float* row = logits + (long)blockIdx.x * V;
-  unsigned long long best = 0ull;
-  for (int i = threadIdx.x; i < V; i += 1024) {
-    const unsigned long long key = mk_key(row[i], i);
-    best = key > best ? key : best;
-  }
-  s[threadIdx.x] = best;
+  s[threadIdx.x] = scan_row_max(row, V);
   if (threadIdx.x == 0) ncand = 0;
   bitonic_desc_1024(s);
   const unsigned long long thr = s[min(k, 1024) - 1];
   __syncthreads();
   cand[threadIdx.x] = 0ull;
   __syncthreads();
-  for (int i = threadIdx.x; i < V; i += 1024) {
-    const unsigned long long key = mk_key(row[i], i);
-    if (key >= thr) {
-      const int slot = atomicAdd(&ncand, 1);
-      if (slot < 1024) cand[slot] = key;
+  if ((V & 3) == 0) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+    const float thr_v = key_val(thr);                       // cheap float pre-filter, exact key compare after
+    for (int i = threadIdx.x; i < (V >> 2); i += 4 * 1024) {
+      f32x4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = (i + u * 1024 < (V >> 2)) ? r4[i + u * 1024] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (q[u][e] >= thr_v && i + u * 1024 < (V >> 2)) {
+            const unsigned long long key = mk_key(q[u][e], (i + u * 1024) * 4 + e);
+            if (key >= thr) { const int slot = atomicAdd(&ncand, 1); if (slot < 1024) cand[slot] = key; }
+          }
+    }
+  } else {
+    for (int i = threadIdx.x; i < V; i += 1024) {
+      const unsigned long long key = mk_key(row[i], i);
+      if (key >= thr) { const int slot = atomicAdd(&ncand, 1); if (slot < 1024) cand[slot] = key; }
     }
   }
   __syncthreads();
@@ -360,6 +394,14 @@ extern "C" int umb_mask_eos(float* logits_row, const int* eos, int n_eos, hipStr
 
 extern "C" int umb_write_token(int* tokens_all, const int* n_ptr, const int* src, hipStream_t st) {
   hipLaunchKernelGGL(write_token_kernel, dim3(1), dim3(1), 0, st, tokens_all, n_ptr, src);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+// diagnostic: n dependent trivial launches (dispatch-cadence measurement)
+__global__ void noop_kernel(int* p) { if (p && threadIdx.x == 1000) *p = 0; }
+extern "C" int umb_bench_launch(int n, int blocks, int* p, hipStream_t st) {
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(noop_kernel, dim3(blocks), dim3(256), 0, st, p);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

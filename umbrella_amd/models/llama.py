@@ -49,17 +49,20 @@ class PackedLinear:
         return _align(N * K * 2), 0
 
     @classmethod
-    def from_dense(cls, w: torch.Tensor, out=None, force_s1=False):
-        """w [N, K] fp16/bf16 on the GPU (HF row-major)."""
+    def from_dense(cls, w: torch.Tensor, out=None, force_s1=False, interleave=False):
+        """w [N, K] fp16/bf16 on the GPU (HF row-major).  interleave: w is a fused [gate; up] stack whose
+        rows are stored as (gate_m, up_m) pairs (SiLU*up becomes the GEMM epilogue; implies S == 1)."""
         N, K = w.shape
         assert N % 16 == 0 and K % 128 == 0, (N, K)
         w = w.contiguous()
         buf = out if out is not None else torch.empty(N * K * 2, dtype=torch.uint8, device=w.device)
-        _lib.call("umb_repack_dense", buf, w, N, K, _lib.dtype_code(w.dtype))
-        return cls(N, K, False, buf, None, force_s1)
+        _lib.call("umb_repack_dense", buf, w, N, K, int(interleave), _lib.dtype_code(w.dtype))
+        lin = cls(N, K, False, buf, None, force_s1 or interleave)
+        lin.interleaved = bool(interleave)
+        return lin
 
     @classmethod
-    def from_awq(cls, qweight, qzeros, scales, group=128, out_w=None, out_meta=None):
+    def from_awq(cls, qweight, qzeros, scales, group=128, out_w=None, out_meta=None, interleave=False):
         """AutoAWQ GEMM tensors on the GPU: qweight [K, N/8] i32, qzeros [K/G, N/8] i32, scales [K/G, N] fp16."""
         K, N = qweight.shape[0], qweight.shape[1] * 8
         assert N % 16 == 0 and K % 128 == 0 and group == 128, (N, K, group)
@@ -67,8 +70,10 @@ class PackedLinear:
         w = out_w if out_w is not None else torch.empty(wb, dtype=torch.uint8, device=qweight.device)
         meta = out_meta if out_meta is not None else torch.empty(mb, dtype=torch.uint8, device=qweight.device)
         _lib.call("umb_awq_repack", w, meta, qweight.contiguous(), qzeros.contiguous(),
-                  scales.to(torch.float16).contiguous(), N, K, group)
-        return cls(N, K, True, w, meta)
+                  scales.to(torch.float16).contiguous(), N, K, group, int(interleave))
+        lin = cls(N, K, True, w, meta, force_s1=interleave)
+        lin.interleaved = bool(interleave)
+        return lin
 
     def struct(self, w_ptr=None, meta_ptr=None) -> UmbLinear:
         s = UmbLinear()
@@ -76,6 +81,15 @@ class PackedLinear:
         s.meta = (self.meta.data_ptr() if self.meta is not None else 0) if meta_ptr is None else meta_ptr
         s.N, s.K, s.awq, s.R, s.S = self.N, self.K, self.awq, self.R, self.S
         return s
+
+    def apply_silu(self, x: torch.Tensor) -> torch.Tensor:
+        """interleaved [gate; up] linear: x [T, K] -> act [T, N/2] = SiLU(gate) * up in x.dtype."""
+        assert getattr(self, "interleaved", False) and self.S == 1
+        T = x.shape[0]
+        act = torch.empty(T, self.N // 2, dtype=x.dtype, device=x.device)
+        _lib.call("umb_gemm", act, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, 1, self.R, 2,
+                  _lib.dtype_code(x.dtype))
+        return act
 
     def apply(self, x: torch.Tensor, round_out=False) -> torch.Tensor:
         """x [T, K] 16-bit -> fp32 [T, N] (split-K partials summed in split order)."""
@@ -151,14 +165,20 @@ class Llama(LLMBase):
         if os.environ.get("UMBRELLA_SYNTHETIC", "1") != "1":
             raise FileNotFoundError(f"no checkpoint for {self.model_name} and UMBRELLA_SYNTHETIC=0")
         gen = torch.Generator(device=dev).manual_seed(self._seed)
+        # GPT-2 style scaled init: projections that write into the residual stream get std / sqrt(2L),
+        # which keeps a random-init 80-layer stack from chaotically amplifying 1-ulp differences
+        resid_scale = 1.0 / math.sqrt(2.0 * c.num_hidden_layers)
 
         def synth(name, shape, kind):
             if kind == "norm":
                 return torch.ones(shape, dtype=self.dtype, device=dev)
             if kind == "embed":
                 return synth_tensor(shape, 1.0, self.dtype, dev, gen)
-            return synth_tensor(shape, 0.02 if kind == "linear" else 0.05, self.dtype, dev, gen)
-        synth.gen = gen
+            std = 0.02 if kind == "linear" else 0.05
+            if name.endswith("o_proj.weight") or name.endswith("down_proj.weight"):
+                std *= resid_scale
+            return synth_tensor(shape, std, self.dtype, dev, gen)
+        synth.gen, synth.resid_scale = gen, resid_scale
         return synth
 
     def _load_linear_group(self, fetch, prefix, names, slab, cursor):
@@ -167,6 +187,7 @@ class Llama(LLMBase):
         shapes = linear_shapes(c)
         N = sum(shapes[n][0] for n in names)
         K = shapes[names[0]][1]
+        il = names[0] == "mlp.gate_proj"          # fused [gate; up]: interleave rows, SiLU*up in the GEMM epilogue
         wb, mb = PackedLinear.packed_bytes(N, K, c.awq)
         w_view = slab[cursor:cursor + (N * K // 2 if c.awq else N * K * 2)]
         meta_view = slab[cursor + wb:cursor + wb + (N // 16) * (K // 128) * 48] if c.awq else None
@@ -175,17 +196,18 @@ class Llama(LLMBase):
             for n in names:
                 base = prefix + n
                 if getattr(fetch, "gen", None) is not None:
-                    parts.append(synth_awq_tensors(shapes[n][0], K, c.awq_group, self.device, fetch.gen))
+                    std = 0.02 * (fetch.resid_scale if n in ("self_attn.o_proj", "mlp.down_proj") else 1.0)
+                    parts.append(synth_awq_tensors(shapes[n][0], K, c.awq_group, self.device, fetch.gen, std))
                 else:
                     parts.append((fetch(base + ".qweight", None, "q"), fetch(base + ".qzeros", None, "q"),
                                   fetch(base + ".scales", None, "q")))
             qw = torch.cat([p[0] for p in parts], dim=1)
             qz = torch.cat([p[1] for p in parts], dim=1)
             sc = torch.cat([p[2] for p in parts], dim=1)
-            lin = PackedLinear.from_awq(qw, qz, sc, c.awq_group, out_w=w_view, out_meta=meta_view)
+            lin = PackedLinear.from_awq(qw, qz, sc, c.awq_group, out_w=w_view, out_meta=meta_view, interleave=il)
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
-            lin = PackedLinear.from_dense(w, out=w_view)
+            lin = PackedLinear.from_dense(w, out=w_view, interleave=il)
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
 
@@ -296,9 +318,9 @@ class Llama(LLMBase):
         w["q"] = torch.zeros(T, QD, dtype=dt, device=dev)
         w["attn"] = torch.zeros(T, QD, dtype=dt, device=dev)
         w["act"] = torch.zeros(T, I, dtype=dt, device=dev)
-        part = max(S * T * N for (N, K, S) in self._plans.values())
+        part = max(S * T * N for (N, K, S) in self._plans.values()) + 64
         w["partial"] = torch.empty(part, dtype=torch.float32, device=dev)
-        self.attn_chunk = max(256, (self.max_length // 8 + 31) // 32 * 32)
+        self.attn_chunk = max(128, (self.max_length // 16 + 31) // 32 * 32)
         self.attn_splits = (self.max_length + self.attn_chunk - 1) // self.attn_chunk
         w["po"] = torch.empty(self.attn_splits * T * QD, dtype=torch.float32, device=dev)
         w["ml"] = torch.empty(self.attn_splits * T * c.num_attention_heads * 2, dtype=torch.float32, device=dev)
