@@ -88,7 +88,7 @@ def kernel_roofline(eng, reps=40):
         lin0 = m.layers[0][key]
         x = x_by_k.setdefault(lin0.K, torch.randn(T, lin0.K, device=m.device).to(m.dtype))
         part = m._bufs["partial"]
-        per_launch = (lin0.N * lin0.K // 2 + (lin0.N // 16) * (lin0.K // 128) * 48) if lin0.awq else lin0.N * lin0.K * 2
+        per_launch = (lin0.N * lin0.K // 2 + (lin0.N // 16) * (lin0.K // 128) * 64) if lin0.awq else lin0.N * lin0.K * 2
         L = m.num_layers
 
         def launch(i):

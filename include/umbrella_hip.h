@@ -32,7 +32,7 @@ typedef struct ihipStream_t* umb_stream_t;   /* == hipStream_t */
 int umb_repack_dense(void* out, const void* w, int N, int K, int interleave, int dtype, umb_stream_t stream);
 /* AutoAWQ GEMM tensors (umbrella/quantization/awq_utils.py:20-27: qweight [K][N/8] i32,
  * qzeros [K/128][N/8] i32, scales [K/128][N] fp16) -> int4 tile order.
- * outw: N*K/2 bytes, meta: (N/16)*(K/128)*48 bytes (16 fp16 scales + 16 u8 zeros per tile). */
+ * outw: N*K/2 bytes, meta: (N/16)*(K/128)*64 bytes (16 x {fp16 scale, fp16 zero} per tile). */
 int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
                    int N, int K, int group, int interleave, umb_stream_t stream);
 

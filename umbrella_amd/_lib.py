@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libumbrella_hip.so")
+LIB_PATH = os.environ.get("UMB_LIB_PATH") or os.path.join(_HERE, "csrc", "libumbrella_hip.so")   # override: experiments only
 
 F16, BF16 = 0, 1
 

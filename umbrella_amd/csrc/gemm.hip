@@ -22,6 +22,7 @@
 //     reduces them in a fixed order -> results are bit-identical for any T
 //     (batch-invariant), which is what makes greedy spec == greedy AR exact.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ repack (load time)
 template <typename P>
@@ -70,11 +71,14 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
     w[s] = d;
   }
   u32x4 v = {w[0], w[1], w[2], w[3]};
-  outw[gid] = v;
-  if (g == 0) {   // per (tile, column): fp16 scale + u8 zero  -> meta[tile][16 x fp16 | 16 x u8]
-    unsigned char* m = meta + tile * 48;
-    reinterpret_cast<u16*>(m)[i] = scales[(long)kg * N + n];
-    m[32 + i] = (unsigned char)((qzeros[(long)kg * NW + (n >> 3)] >> sh) & 0xFu);
+  // tile order [N/64][K/128][4]: the four n-tiles a block works on are adjacent, so each 128-k step of a
+  // block is one contiguous 4 KiB HBM burst (1 KiB bursts per wave measured ~25 % slower)
+  const long otile = ((long)(nt >> 2) * KG + kg) * 4 + (nt & 3);
+  outw[otile * 64 + lane] = v;
+  if (g == 0) {   // per (tile, column): {fp16 scale, fp16(zero)} pairs -> meta[tile][16][2] (64 B)
+    u16* m = reinterpret_cast<u16*>(meta + otile * 64);
+    m[2 * i] = scales[(long)kg * N + n];
+    m[2 * i + 1] = F16::from_f((float)((qzeros[(long)kg * NW + (n >> 3)] >> sh) & 0xFu));
   }
 }
 
@@ -84,25 +88,31 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
 // -> conflict-free ds_read_b128, 4x less L2->L1 traffic than per-wave loads (the int4 path reads
 // 4 KiB of activations per 1 KiB weight tile, so unshared B loads were the bottleneck).
 // Weight tiles go straight from HBM to VGPRs (non-temporal), double buffered across 128-k blocks.
+// AWQ modes: 0 dense 16-bit weights; 1 int4, dequant folded out of the MFMA (any activation dtype);
+// 2 int4 with exact fp16 dequant in registers, W = fp16((q - z) * s) -- bit-identical to what
+// awq_ext.dequantize_weights_cuda produces -- via v_pk_add_f16 / v_pk_mul_f16 (fp16 activations only).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
 template <typename P, int AWQ, int R> struct Stage {
   u32x4 a[R][AWQ ? 1 : 4];
-  uint2 sc[AWQ ? R : 1];
-  unsigned zz[AWQ ? R : 1];
+  u32x4 m4[AWQ == 1 ? R : 1];     // folded path: 4 x {scale, zero} for output rows g*4 .. g*4+3
+  unsigned m1[AWQ == 2 ? R : 1];  // exact path : {scale, zero} of this lane's weight row
 };
 
 template <typename P, int AWQ, int R>
 __device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const u32x4* __restrict__ wp,
                                            const unsigned char* __restrict__ meta, int nt0, int KB, int kb,
                                            int lane) {
-  const int g = lane >> 4;
+  const int g = lane >> 4, i = lane & 15;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (AWQ) {
-      const long tile = (long)(nt0 + r) * KB + kb;
+      const int nt = nt0 + r;
+      const long tile = ((long)(nt >> 2) * KB + kb) * 4 + (nt & 3);
       st.a[r][0] = __builtin_nontemporal_load(wp + tile * 64 + lane);
-      const unsigned char* m = meta + tile * 48;
-      st.sc[r] = *reinterpret_cast<const uint2*>(m + g * 8);
-      st.zz[r] = *reinterpret_cast<const unsigned*>(m + 32 + g * 4);
+      const unsigned char* m = meta + tile * 64;
+      if (AWQ == 1) st.m4[r] = *reinterpret_cast<const u32x4*>(m + g * 16);
+      else st.m1[r] = *reinterpret_cast<const unsigned*>(m + i * 4);
     } else {
       const u32x4* p = wp + ((long)(nt0 + r) * KB + kb) * 256 + lane;   // 4 tiles (128 k) contiguous
 #pragma unroll
@@ -120,7 +130,46 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
   for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
-  if (AWQ) {
+  if (AWQ == 2) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned mm = st.m1[r];
+      const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
+      const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
+      const h2 s2 = {sc, sc};
+      const _Float16 nz = -((_Float16)1024.0f + zf);          // exact: |1024 + z| <= 1039
+      const _Float16 nz16 = -((_Float16)64.0f + zf);
+      const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
+      const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned w = st.a[r][0][s];
+        const unsigned w8 = w >> 8;
+        u32x4 f;
+        // nibbles at mantissa bits 0..3 give fp16(1024 + q); at bits 4..7 fp16(1024 + 16 q): one shift per
+        // dword instead of three.  (q - z) is exact in fp16 either way, then one rounding in (q - z) * s.
+        const h2 t0 = __builtin_bit_cast(h2, (w & 0x000F000Fu) | 0x64006400u);
+        const h2 t1 = __builtin_bit_cast(h2, (w & 0x00F000F0u) | 0x64006400u);
+        const h2 t2 = __builtin_bit_cast(h2, (w8 & 0x000F000Fu) | 0x64006400u);
+        const h2 t3 = __builtin_bit_cast(h2, (w8 & 0x00F000F0u) | 0x64006400u);
+#ifdef UMB_EXP_NODEQ
+        f[0] = w; f[1] = w8; f[2] = w + 1; f[3] = w8 + 1;
+#else
+        f[0] = __builtin_bit_cast(unsigned, (t0 + nz2) * s2);
+        f[1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t1, sixteenth, nz16_2) * s2);
+        f[2] = __builtin_bit_cast(unsigned, (t2 + nz2) * s2);
+        f[3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t3, sixteenth, nz16_2) * s2);
+#endif
+#ifdef UMB_EXP_NOMFMA
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) { acc[r][tt][0] += __uint_as_float(f[0] ^ b[tt][s][0]); acc[r][tt][1] += __uint_as_float(f[1] ^ f[2] ^ f[3]); }
+#else
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[r][tt] = P::mfma(f, b[tt][s], acc[r][tt]);
+#endif
+      }
+    }
+  } else if (AWQ == 1) {
     const u32x4 ones = {P::ONE2, P::ONE2, P::ONE2, P::ONE2};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[TT];
@@ -146,18 +195,17 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) ga[tt] = P::mfma(f, b[tt][s], ga[tt]);
       }
-      const float s0 = F16::to_f((u16)(st.sc[r].x & 0xffffu)), s1 = F16::to_f((u16)(st.sc[r].x >> 16));
-      const float s2 = F16::to_f((u16)(st.sc[r].y & 0xffffu)), s3 = F16::to_f((u16)(st.sc[r].y >> 16));
-      const unsigned z = st.zz[r];
-      const float z0 = (float)(z & 0xffu) + P::MAGIC_OFF, z1 = (float)((z >> 8) & 0xffu) + P::MAGIC_OFF;
-      const float z2 = (float)((z >> 16) & 0xffu) + P::MAGIC_OFF, z3 = (float)(z >> 24) + P::MAGIC_OFF;
+      float sc[4], zo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = F16::to_f((u16)(st.m4[r][e] & 0xffffu));
+        zo[e] = F16::to_f((u16)(st.m4[r][e] >> 16)) + P::MAGIC_OFF;
+      }
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         const float sx = xs[tt][0];
-        acc[r][tt][0] += s0 * (ga[tt][0] - z0 * sx);
-        acc[r][tt][1] += s1 * (ga[tt][1] - z1 * sx);
-        acc[r][tt][2] += s2 * (ga[tt][2] - z2 * sx);
-        acc[r][tt][3] += s3 * (ga[tt][3] - z3 * sx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][tt][e] += sc[e] * (ga[tt][e] - zo[e] * sx);
       }
     }
   } else {
@@ -215,32 +263,47 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     }
   };
   auto store_x = [&](int c) {
+#ifdef UMB_EXP_NOX
+    if (c > 1) return;
+#endif
 #pragma unroll
     for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
   };
 
-  Stage<P, AWQ, R> s0, s1;
+  // ring of PF = 2*CB weight stages: PF x R tiles of 1 KiB loads in flight per wave
+  constexpr int PF = 2 * CB;
+  Stage<P, AWQ, R> st[PF];
   load_x(0);
-  if (active && kb0 < kb1) stage_load<P, AWQ, R>(s0, wp, meta, nt0, KB, kb0, lane);
-  for (int c = 0; c < nchunks; ++c) {
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (kb0 + i < kb1) stage_load<P, AWQ, R>(st[i], wp, meta, nt0, KB, kb0 + i, lane);
+  }
+  auto chunk = [&](int c, auto half) {
+    constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
     store_x(c);
+#ifdef UMB_EXP_NOX
+    if (c < 2) __syncthreads();
+    if (c + 1 < 2) load_x(c + 1);
+#else
     __syncthreads();
     if (c + 1 < nchunks) load_x(c + 1);
+#endif
     if (active) {
       const u32x4* xc = xs + (c & 1) * F * 64;
 #pragma unroll
-      for (int kl = 0; kl < CB; kl += 2) {
+      for (int kl = 0; kl < CB; ++kl) {
         const int kb = kb0 + c * CB + kl;
         if (kb < kb1) {
-          if (kb + 1 < kb1) stage_load<P, AWQ, R>(s1, wp, meta, nt0, KB, kb + 1, lane);
-          stage_compute<P, AWQ, TT, R>(s0, xc + kl * TT * 4 * 64, lane, acc);
-          if (kb + 1 < kb1) {
-            if (kb + 2 < kb1) stage_load<P, AWQ, R>(s0, wp, meta, nt0, KB, kb + 2, lane);
-            stage_compute<P, AWQ, TT, R>(s1, xc + (kl + 1) * TT * 4 * 64, lane, acc);
-          }
+          stage_compute<P, AWQ, TT, R>(st[H * CB + kl], xc + kl * TT * 4 * 64, lane, acc);
+          if (kb + PF < kb1) stage_load<P, AWQ, R>(st[H * CB + kl], wp, meta, nt0, KB, kb + PF, lane);
         }
       }
     }
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    chunk(c, std::integral_constant<int, 0>{});
+    if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
   }
   if (!active) return;
 
@@ -273,7 +336,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out) {
   const int NT = N / 16, KB = K / 128;
   int R = 1;
-  if (NT % 2 == 0 && NT >= 4096) R = 2;
+  if (!awq && NT % 2 == 0 && NT >= 4096) R = 2;   // int4 tile order is tied to R == 1 (4 n-tiles per block)
   int S = 1;
   if (!force_s1) {
     const int nblk = (NT + 4 * R - 1) / (4 * R);
@@ -331,6 +394,9 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
 extern "C" int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
                         int awq, int S, int R, int epi, int dtype, hipStream_t st) {
   if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 2 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
+  if (awq && (N % 64 || R != 1)) return UMB_EINVAL;
+  if (awq && dtype == UMB_F16)     // exact fp16 dequant in registers (same W as the reference's dequantize kernel)
+    return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
   DISPATCH_DTYPE(dtype, {
     if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
     return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
@@ -348,10 +414,10 @@ extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int inte
   return UMB_OK;
 }
 
-// outw: N*K/2 bytes; meta: (N/16)*(K/128)*48 bytes
+// outw: N*K/2 bytes; meta: (N/16)*(K/128)*64 bytes
 extern "C" int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
                               int N, int K, int group, int interleave, hipStream_t st) {
-  if (N % 16 || K % 128 || group != 128) return UMB_EINVAL;
+  if (N % 64 || K % 128 || group != 128) return UMB_EINVAL;
   const long total = (long)(N / 16) * (K / 128) * 64;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipLaunchKernelGGL(repack_awq_kernel, grid, block, 0, st, (const unsigned*)qweight, (const unsigned*)qzeros,

@@ -45,7 +45,7 @@ class PackedLinear:
     @staticmethod
     def packed_bytes(N, K, awq):
         if awq:
-            return _align(N * K // 2), _align((N // 16) * (K // 128) * 48)
+            return _align(N * K // 2), _align((N // 16) * (K // 128) * 64)
         return _align(N * K * 2), 0
 
     @classmethod
@@ -190,7 +190,7 @@ class Llama(LLMBase):
         il = names[0] == "mlp.gate_proj"          # fused [gate; up]: interleave rows, SiLU*up in the GEMM epilogue
         wb, mb = PackedLinear.packed_bytes(N, K, c.awq)
         w_view = slab[cursor:cursor + (N * K // 2 if c.awq else N * K * 2)]
-        meta_view = slab[cursor + wb:cursor + wb + (N // 16) * (K // 128) * 48] if c.awq else None
+        meta_view = slab[cursor + wb:cursor + wb + (N // 16) * (K // 128) * 64] if c.awq else None
         if c.awq:
             parts = []
             for n in names:
@@ -446,5 +446,5 @@ class Llama(LLMBase):
         per_layer = 0
         for lins in self.layers[:1]:
             for ln in lins.values():
-                per_layer += (ln.N * ln.K // 2 + (ln.N // 16) * (ln.K // 128) * 48) if ln.awq else ln.N * ln.K * 2
+                per_layer += (ln.N * ln.K // 2 + (ln.N // 16) * (ln.K // 128) * 64) if ln.awq else ln.N * ln.K * 2
         return per_layer * self.num_layers + self.lm_head.N * self.lm_head.K * 2
