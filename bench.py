@@ -110,68 +110,62 @@ def kernel_roofline(eng, reps=40):
 
 
 def cpu_baseline(wl, gm, accept_len, threads):
-    """Oracle ("port") timed on host cores on a bounded sample of the same workload: one static 3x4
-    iteration where the 70B-AWQ-shaped target is truncated to 1 of its 80 layers and the 1B draft to
-    2 of its 16 layers (per-layer cost extrapolated linearly; lm_head / embedding timed in full)."""
+    """Oracle ("port") timed on host cores on a bounded sample of the same workload: one static-tree
+    iteration with the target truncated to 1 of its layers and the draft to 2 (per-layer cost extrapolated
+    linearly; embedding + lm_head timed in full).  AWQ linears are dequantised once at load (what a CPU port
+    would do) and all arithmetic is fp32 on the torch CPU backend."""
+    import copy
     from oracle.model import OracleLlama
     from umbrella_amd.models.config import KNOWN, rope_inv_freq
     from umbrella_amd.models.synthetic import linear_shapes
     torch.set_num_threads(threads)
     T = gm["size"]
-    out = {}
 
-    def time_model(name, layers, awq, rows_list):
-        import copy
-        import numpy as np
+    def time_model(name, layers, rows_list):
         cfg = copy.copy(KNOWN[name])
         full_layers = cfg.num_hidden_layers
         cfg.num_hidden_layers = layers
-        g = torch.Generator().manual_seed(0)
-        sd = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g, dtype=torch.bfloat16),
-              "model.norm.weight": torch.ones(cfg.hidden_size, dtype=torch.bfloat16)}
+        sd = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, cfg.hidden_size) * 0.02,
+              "model.norm.weight": torch.ones(cfg.hidden_size)}
         if not cfg.tie_word_embeddings:
             sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
         for i in range(layers):
             p = f"model.layers.{i}."
             for ln, (n, k) in linear_shapes(cfg).items():
-                if awq:
-                    sd[p + ln + ".qweight"] = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32, generator=g)
-                    sd[p + ln + ".qzeros"] = torch.randint(-2**31, 2**31 - 1, (k // 128, n // 8), dtype=torch.int32, generator=g)
-                    sd[p + ln + ".scales"] = (torch.rand(k // 128, n, generator=g) * 0.01).half()
-                else:
-                    sd[p + ln + ".weight"] = torch.randn(n, k, generator=g, dtype=torch.bfloat16) * 0.02
-            sd[p + "input_layernorm.weight"] = torch.ones(cfg.hidden_size, dtype=torch.bfloat16)
-            sd[p + "post_attention_layernorm.weight"] = torch.ones(cfg.hidden_size, dtype=torch.bfloat16)
+                sd[p + ln + ".weight"] = torch.randn(n, k) * 0.02
+            sd[p + "input_layernorm.weight"] = torch.ones(cfg.hidden_size)
+            sd[p + "post_attention_layernorm.weight"] = torch.ones(cfg.hidden_size)
         inv, sc = rope_inv_freq(cfg)
-        m = OracleLlama(cfg, sd, inv, sc, max_length=256, dtype=torch.bfloat16)
+        m = OracleLlama(cfg, sd, inv, sc, max_length=256, dtype=torch.float32)
         P = 128                                   # prefix already "in the cache" (zeros: timing only)
-        # layers-only cost is separated from embedding + lm_head by a second, 0-layer measurement
         total = 0.0
         for rows in rows_list:
             ids = torch.randint(3, 1000, (1, rows))
             pos = torch.arange(P, P + rows)[None]
             mk = torch.ones(rows, 256, dtype=torch.bool)
-            t0 = time.time()
-            m.kv_cache.kv_offset = P
-            m.inference(ids, pos, mk, torch.arange(P, P + rows))
-            t_all = time.time() - t0
-            nl = m.num_layers
-            m.num_layers = 0
-            t0 = time.time()
-            m.inference(ids, pos, mk, torch.arange(P, P + rows))
-            t_head = time.time() - t0
-            m.num_layers = nl
-            total += (t_all - t_head) / layers * full_layers + t_head
+            best_all, best_head = 1e9, 1e9
+            for _ in range(2):                    # second pass = warm caches / thread pool
+                m.kv_cache.kv_offset = P
+                t0 = time.time()
+                m.inference(ids, pos, mk, torch.arange(P, P + rows))
+                best_all = min(best_all, time.time() - t0)
+                nl, m.num_layers = m.num_layers, 0
+                m.kv_cache.kv_offset = P
+                t0 = time.time()
+                m.inference(ids, pos, mk, torch.arange(P, P + rows))
+                best_head = min(best_head, time.time() - t0)
+                m.num_layers = nl
+            total += (best_all - best_head) / layers * full_layers + best_head
         return total
 
     widths = [len(x) for x in gm["roots"]]
-    t_draft = time_model(wl["draft"], 2, False, widths)
-    t_target = time_model(wl["target"], 1, KNOWN[wl["target"]].awq, [T])
+    t_draft = time_model(wl["draft"], 2, widths)
+    t_target = time_model(wl["target"], 1, [T])
     it = t_draft + t_target
-    return {"value": accept_len / it, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU, bf16) on 1 static {len(widths)-1}-level iteration: draft truncated to 2/16 layers, "
-                      f"target to 1/80 layers, per-layer time extrapolated linearly, lm_head timed in full; "
-                      f"iteration {it:.1f} s at the same accept_len {accept_len:.2f}"}
+    return {"value": round(accept_len / it, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch CPU fp32, AWQ dequantised at load) on 1 static {len(widths)-1}-level iteration: draft "
+                      f"truncated to 2 of its layers, target to 1 of its layers, per-layer time extrapolated linearly, "
+                      f"embedding + lm_head timed in full; extrapolated iteration {it:.2f} s at the same accept_len {accept_len:.2f}"}
 
 
 def main():
@@ -305,7 +299,7 @@ def main():
                                "layer_gemms_GBs": round(tot_b / tot_us / 1e3, 1)}
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(wl, gm, accept_len, os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(wl, gm, accept_len, torch.get_num_threads())
             except Exception as e:                                        # never lose the GPU line to the baseline leg
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

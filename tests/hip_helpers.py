@@ -23,7 +23,7 @@ def growmap(name="3x4"):
 def hip_model(cfgd, seed, max_length, dtype, device, awq=False, eos=(3, 5), **kw):
     cfg = LlamaCfg(**dict(cfgd, eos_token_id=list(eos), awq=awq))
     sd = synth_awq_small(cfg, seed) if awq else synth_state_small(cfg, seed)
-    alloc_kw = {k: kw.pop(k) for k in ("exit_layer", "num_cache_layers") if k in kw}
+    alloc_kw = {k: kw.pop(k) for k in ("exit_layer", "num_cache_layers", "layer_range") if k in kw}
     m = Llama("tiny", max_length=max_length, device=str(device), dtype=dtype, state_dict=sd, config=cfg, **kw)
     m.alloc(**alloc_kw)
     return m, sd

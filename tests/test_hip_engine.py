@@ -219,3 +219,52 @@ def test_reference_face_and_awq_linear(dev):
     assert out.shape == (1, 5, N) and out.dtype == torch.float16
     ref = O.awq_linear(x[0].float(), Mod.qweight, Mod.qzeros, Mod.scales, 128)
     assert (out[0].cpu().float() - ref).abs().max() < 0.02 * ref.abs().max()
+
+
+def test_pipeline_stages_match_full_model(dev):
+    """Two layer-sharded stage models chained by hand == the whole model (bitwise): stage 0 embeds and
+    runs layers [0,2), stage 1 resolves indices only, runs [2,4), final norm and lm_head."""
+    from hip_helpers import hip_model
+    dtype = torch.bfloat16
+    full, sd = hip_model(G["target_cfg"], G["seeds"]["target"], 128, dtype, dev)
+    s0, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 128, dtype, dev, layer_range=(0, 2))
+    s1, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 128, dtype, dev, layer_range=(2, 4))
+    assert s0.is_first and not s0.is_last and s1.is_last and not s1.is_first and s1.num_layers == 2
+    ids = torch.tensor(PROMPT_S, dtype=torch.int32, device=dev)
+    T = ids.shape[0]
+    pos = torch.arange(T, dtype=torch.int32, device=dev)
+    pre = torch.zeros(1, dtype=torch.int32, device=dev)
+    full.forward_explicit(ids, pos, pos, pre, head_from=0)
+    ref = full.logits_buffer[:T].clone()
+    s0.forward_explicit(ids, pos, pos, pre, head_from=0)
+    s1.hidden_buffer[:T].copy_(s0.hidden_buffer[:T])
+    s1.forward_explicit(ids, pos, pos, pre, head_from=0)
+    assert torch.equal(s1.logits_buffer[:T], ref)
+    # the stages hold disjoint KV slices
+    assert torch.equal(s0.kv_cache.k, full.kv_cache.k[:2]) and torch.equal(s1.kv_cache.vt, full.kv_cache.vt[2:])
+
+
+def test_pipelined_engine_single_rank(dev):
+    """PipelinedStaticEngine with a 1-rank group (RCCL world 1) == the plain static engine."""
+    import os
+    import torch.distributed as dist
+    from hip_helpers import growmap, hip_model, static_engine
+    from umbrella_amd.parallel import OP_STOP, PipelineComm, PipelinedStaticEngine
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    dtype = torch.bfloat16
+    ref_eng, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=False)
+    ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        stage, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 256, dtype, dev, layer_range=(0, 4))
+        draft, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 256, dtype, dev, cuda_graph=True)
+        comm = PipelineComm(0, 1, dev, G["target_cfg"]["hidden_size"], dtype, 64, 5)
+        eng = PipelinedStaticEngine("d", "t", dtype=dtype, device=str(dev), growmap=growmap("3x4"), max_length=256,
+                                    safe_buffer=16, stop_distance=8, draft_model_obj=draft, tokenizer=IdTokenizer(),
+                                    stage_model=stage, comm=comm)
+        eng.initialize()
+        out = eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+        assert out == ref
+    finally:
+        dist.destroy_process_group()

@@ -174,11 +174,12 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
   int tok, p, s, pre;
   if (tokens_all) {
     const int n = *n_ptr;
-    tok = tokens_all[n + off + i]; p = n + depth[off + i]; s = n + off + i; pre = n;
+    tok = table ? tokens_all[n + off + i] : 0; p = n + depth[off + i]; s = n + off + i; pre = n;
   } else {
-    tok = tok_in[i]; p = pos_in[i]; s = slot_in[i]; pre = *prefix_in;
+    tok = table ? tok_in[i] : 0; p = pos_in[i]; s = slot_in[i]; pre = *prefix_in;
   }
   if (threadIdx.x == 0) { pos_out[i] = p; slot_out[i] = s; if (i == 0) *prefix_out = pre; }
+  if (!table) return;                        // pipeline stages > 0: indices only, activations arrive from the previous stage
   const u32x4* src = reinterpret_cast<const u32x4*>(table + (long)tok * H);
   u32x4* dst = reinterpret_cast<u32x4*>(x + (long)i * H);
   for (int k = threadIdx.x; k < H / 8; k += 256) dst[k] = src[k];

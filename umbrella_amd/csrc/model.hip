@@ -31,8 +31,8 @@ static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
     CK(umb_embed_prep(ws->h, m->embed, m->H, s->T, s->tokens, s->positions, s->slots, s->prefix_len, s->tokens_all,
                       s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix, m->dtype, st));
   } else {
-    // reuse embed_prep for its index side effects only: gather into the (unused here) xn buffer
-    CK(umb_embed_prep(ws->xn, m->embed, m->H, s->T, s->tokens, s->positions, s->slots, s->prefix_len, s->tokens_all,
+    // pipeline stage > 0: resolve indices only (table == NULL skips the gather); ws->h holds the incoming activations
+    CK(umb_embed_prep(ws->xn, nullptr, m->H, s->T, s->tokens, s->positions, s->slots, s->prefix_len, s->tokens_all,
                       s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix, m->dtype, st));
   }
   return UMB_OK;

@@ -216,17 +216,28 @@ class Llama(LLMBase):
         _lib.load()
         exit_layer = kwargs.pop("exit_layer", -1)
         self.num_cache_layers = kwargs.get("num_cache_layers", 0)
-        L = c.num_hidden_layers
+        Lfull = c.num_hidden_layers
         if self.cuda_graph and exit_layer and exit_layer > 0:          # llama.py:421,450-451
-            L = min(L, exit_layer)
+            Lfull = min(Lfull, exit_layer)
+        # layer_range=(lo, hi): this process holds one pipeline stage (layers lo..hi-1 of the model)
+        lo, hi = kwargs.pop("layer_range", None) or (0, Lfull)
+        self.layer_lo, self.layer_hi, self.is_first, self.is_last = lo, hi, lo == 0, hi == Lfull
+        L = hi - lo
         self.num_layers = L
         fetch = self._tensor_source()
+        reseed = getattr(fetch, "gen", None)
         H, V = c.hidden_size, c.vocab_size
-        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed").to(dt).contiguous()
-        head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head").to(dt)
-        self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)
-        del head_w
-        self.norm_weight = fetch("model.norm.weight", (H,), "norm").to(dt).contiguous()
+        if reseed is not None:
+            reseed.manual_seed(self._seed * 1000003)
+        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed").to(dt).contiguous() \
+            if (self.is_first or (self.is_last and c.tie_word_embeddings)) else None
+        if self.is_last:
+            head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head").to(dt)
+            self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)
+            del head_w
+            self.norm_weight = fetch("model.norm.weight", (H,), "norm").to(dt).contiguous()
+        else:
+            self.lm_head, self.norm_weight = None, None
         self.cos_cache, self.sin_cache = (t.to(dev).contiguous() for t in rope_tables(c, self.max_length, dt))
         self.kv_cache = TreeKVCache(L, c.num_key_value_heads, c.head_dim, self.max_length, dev, dt)
 
@@ -242,7 +253,9 @@ class Llama(LLMBase):
         self._layer_structs = (UmbLayer * L)()
         stream_any = False
         for i in range(L):
-            p = f"model.layers.{i}."
+            p = f"model.layers.{lo + i}."
+            if reseed is not None:                   # per-layer seed: a stage's weights do not depend on the split
+                reseed.manual_seed(self._seed * 1000003 + lo + i + 1)
             slab = torch.empty(slab_bytes, dtype=torch.uint8, device=dev)
             cursor, lins = 0, {}
             for key, names in groups:
@@ -279,7 +292,9 @@ class Llama(LLMBase):
                                                                c.num_attention_heads, c.num_key_value_heads,
                                                                c.head_dim, V, self.max_length)
         m.eps, m.attn_scale = c.rms_norm_eps, 1.0 / math.sqrt(c.head_dim)
-        m.embed, m.lm_head, m.final_norm = self.embed_tokens.data_ptr(), self.lm_head.struct(), self.norm_weight.data_ptr()
+        m.embed = self.embed_tokens.data_ptr() if (self.embed_tokens is not None and self.is_first) else 0
+        if self.is_last:
+            m.lm_head, m.final_norm = self.lm_head.struct(), self.norm_weight.data_ptr()
         m.rope_cos, m.rope_sin = self.cos_cache.data_ptr(), self.sin_cache.data_ptr()
         m.k_cache, m.vt_cache = self.kv_cache.k.data_ptr(), self.kv_cache.vt.data_ptr()
         m.layers = C.cast(self._layer_structs, C.POINTER(UmbLayer))
@@ -327,7 +342,7 @@ class Llama(LLMBase):
         w["pos"] = torch.zeros(T, dtype=torch.int32, device=dev)
         w["slot"] = torch.zeros(T, dtype=torch.int32, device=dev)
         w["prefix"] = torch.zeros(1, dtype=torch.int32, device=dev)
-        w["logits"] = torch.empty(T, V, dtype=torch.float32, device=dev)
+        w["logits"] = torch.empty(T if self.is_last else 1, V if self.is_last else 8, dtype=torch.float32, device=dev)
         ws = self._ws = UmbWorkspace()
         ws.h, ws.xn, ws.q, ws.attn, ws.act = (w[k].data_ptr() for k in ("h", "xn", "q", "attn", "act"))
         ws.partial, ws.attn_po, ws.attn_ml = w["partial"].data_ptr(), w["po"].data_ptr(), w["ml"].data_ptr()
@@ -361,9 +376,9 @@ class Llama(LLMBase):
         s.tokens_all, s.n_ptr, s.depth = tokens_all.data_ptr(), n_ptr.data_ptr(), depth.data_ptr()
         s.mask_bits = mask_bits.data_ptr() + tree_off * mask_words * 8
         s.mask_words, s.n_mask_keys = mask_words, tree_off + T
-        s.head_from = head_from
+        s.head_from = head_from if self.is_last else T
         s.layer_begin, s.layer_end = layer_range or (0, self.num_layers)
-        s.skip_embed = int(skip_embed)
+        s.skip_embed = int(skip_embed or not self.is_first)
         self._run(s)
 
     def forward_explicit(self, tokens, positions, slots, prefix_len, mask_bits=None, mask_words=0, n_mask_keys=None,
@@ -377,9 +392,9 @@ class Llama(LLMBase):
         s.mask_bits = mask_bits.data_ptr() if mask_bits is not None else 0
         s.mask_words = mask_words
         s.n_mask_keys = T if n_mask_keys is None else n_mask_keys
-        s.head_from = head_from
+        s.head_from = head_from if self.is_last else T
         s.layer_begin, s.layer_end = layer_range or (0, self.num_layers)
-        s.skip_embed = int(skip_embed)
+        s.skip_embed = int(skip_embed or not self.is_first)
         self._keep = (tokens, positions, slots, prefix_len, mask_bits)
         self._run(s)
 
@@ -447,4 +462,4 @@ class Llama(LLMBase):
         for lins in self.layers[:1]:
             for ln in lins.values():
                 per_layer += (ln.N * ln.K // 2 + (ln.N // 16) * (ln.K // 128) * 64) if ln.awq else ln.N * ln.K * 2
-        return per_layer * self.num_layers + self.lm_head.N * self.lm_head.K * 2
+        return per_layer * self.num_layers + (self.lm_head.N * self.lm_head.K * 2 if self.lm_head is not None else 0)

@@ -1,0 +1,295 @@
+"""Layer-sharded verify across the GPUs of one node (BASELINE config 5; new functionality -- the
+reference has no distributed code at all).
+
+One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
+tests.  Rank 0 owns the draft model, the engine state and pipeline stage 0; rank r owns decoder layers
+[lo_r, hi_r) of the target and their KV slice.  A batch-1 request is a strictly sequential chain of layers,
+so this buys capacity, not speed: per verify the [T, H] activation makes world-1 point-to-point hops
+(213 KB at T = 13 -- latency bound, one direct xGMI link per hop; no ring collective is involved), the last
+stage returns the T sampled ids, and rank 0 broadcasts the accept result so every stage compacts its own
+KV slice.  Token ids are identical to the single-GPU result: same kernels, same order.
+
+Protocol (all from rank 0, one int64[8] control broadcast per forward):
+    [OP_TREE, T]                         tree-mode verify over the engine's tree tables
+    [OP_CHUNK, T, start, want_head]      causal chunk at slots/positions start.. (prefill / append)
+    [OP_COMMIT] + int32[8 + max_path]    accept result + path -> KV compaction, num_nodes update
+    [OP_RESET] / [OP_STOP]
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+OP_STOP, OP_TREE, OP_CHUNK, OP_COMMIT, OP_RESET = 0, 1, 2, 3, 4
+
+
+def split_layers(num_layers: int, world: int):
+    """Contiguous, as even as possible: [(lo, hi)] per rank."""
+    base, rem = divmod(num_layers, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class PipelineComm:
+    """Control + activation plumbing, independent of what a stage computes (CPU-testable with gloo)."""
+
+    def __init__(self, rank: int, world: int, device, hidden: int, dtype, max_tokens: int, max_path: int):
+        self.rank, self.world, self.device = rank, world, device
+        self.ctrl = torch.zeros(8, dtype=torch.int64, device=device)
+        self.h = torch.zeros(max_tokens, hidden, dtype=dtype, device=device)
+        self.ids = torch.zeros(max_tokens, dtype=torch.int32, device=device)
+        self.commit = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=device)
+
+    @property
+    def first(self):
+        return self.rank == 0
+
+    @property
+    def last(self):
+        return self.rank == self.world - 1
+
+    def command(self, *vals):
+        """rank 0: broadcast a control word; other ranks: receive it.  Returns the list of ints."""
+        if self.first:
+            self.ctrl.zero_()
+            self.ctrl[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
+        dist.broadcast(self.ctrl, src=0)
+        return self.ctrl.tolist()
+
+    def recv_activations(self, T):
+        if not self.first:
+            dist.recv(self.h[:T], src=self.rank - 1)
+        return self.h[:T]
+
+    def send_activations(self, h):
+        if not self.last:
+            dist.send(h.contiguous(), dst=self.rank + 1)
+
+    def return_ids(self, ids=None, n=1):
+        """last stage -> rank 0 (no-op when they coincide)."""
+        if self.world == 1:
+            return ids
+        if self.last:
+            dist.send(ids[:n].contiguous(), dst=0)
+            return ids
+        if self.first:
+            dist.recv(self.ids[:n], src=self.world - 1)
+            return self.ids[:n]
+        return None
+
+    def share_commit(self, res=None, path=None):
+        if self.first:
+            self.commit[:8] = res[:8]
+            self.commit[8:8 + path.numel()] = path
+        dist.broadcast(self.commit, src=0)
+        return self.commit[:8], self.commit[8:]
+
+
+class PipelinedTarget:
+    """Drop-in for the engine's ``target_model`` on rank 0: every forward runs stage 0 locally and drives the
+    other stages through PipelineComm; ``sampled`` ids come back from the last stage."""
+
+    def __init__(self, stage_model, comm: PipelineComm, engine):
+        self.m, self.comm, self.eng = stage_model, comm, engine
+        self.config, self.max_length, self.eos_tokens = stage_model.config, stage_model.max_length, stage_model.eos_tokens
+        self.kv_cache, self.CHUNK, self.num_layers = stage_model.kv_cache, stage_model.CHUNK, stage_model.num_layers
+        self._off = None
+
+    def reserve(self, tokens):
+        self.m.reserve(tokens)
+
+    def clear(self):
+        self.comm.command(OP_RESET)
+        self.m.clear()
+
+    def weight_bytes(self):
+        return self.m.weight_bytes()
+
+    # tree-mode verify: returns sampled ids [T] on rank 0
+    def verify_tree(self, tokens_all, n_dev, depth, T, mask_bits, mask_words):
+        self.comm.command(OP_TREE, T)
+        self.m.forward_tree(tokens_all, n_dev, depth, 0, T, mask_bits, mask_words, head_from=0)
+        self.comm.send_activations(self.m.hidden_buffer[:T])
+        return self.comm.return_ids(n=T)
+
+    # causal chunks (prefill / append): returns the arg-max id of the last row (int32[1]) on rank 0
+    def prefill_tokens(self, ids, start, want_logits=True):
+        P = ids.shape[0]
+        out = None
+        for lo in range(0, P, self.CHUNK):
+            hi = min(P, lo + self.CHUNK)
+            T = hi - lo
+            last = hi == P and want_logits
+            self.comm.command(OP_CHUNK, T, start + lo, int(last))
+            pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=self.m.device)
+            pre = torch.tensor([start + lo], dtype=torch.int32, device=self.m.device)
+            local_head = last and self.m.is_last            # single-stage group: the head is here
+            self.m.forward_explicit(ids[lo:hi].contiguous(), pos, pos, pre, head_from=(T - 1 if local_head else T))
+            self.comm.send_activations(self.m.hidden_buffer[:T])
+            if local_head:
+                from . import _lib
+                out = self.eng._first_token(self.m.logits_buffer[0]).clone()
+            elif last:
+                out = self.comm.return_ids(n=1)
+        self.kv_cache.kv_offset = start + P
+        return out
+
+
+def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False):
+    """Event loop of ranks > 0.  `tables` = dict(depth, mask_bits, mask_words, n_dev, eos_dev, n_eos, max_path)."""
+    from . import _lib
+    dev = model.device
+    sampled = torch.zeros(comm.ids.shape[0], dtype=torch.int32, device=dev)
+    dummy_tokens = torch.zeros(model.max_length + comm.ids.shape[0] + 8, dtype=torch.int32, device=dev)
+    n_dev = tables["n_dev"]
+    V = model.config.vocab_size
+    while True:
+        c = comm.command()
+        op = c[0]
+        if op == OP_STOP:
+            return
+        if op == OP_RESET:
+            model.clear()
+            n_dev.zero_()
+        elif op == OP_TREE:
+            T = c[1]
+            comm.recv_activations(T)
+            model.hidden_buffer[:T].copy_(comm.h[:T])
+            model.forward_tree(dummy_tokens, n_dev, tables["depth"], 0, T, tables["mask_bits"], tables["mask_words"],
+                               head_from=0)
+            comm.send_activations(model.hidden_buffer[:T])
+            if comm.last:
+                _lib.call("umb_argmax_rows", sampled, model.logits_buffer, T, V)
+                comm.return_ids(sampled, T)
+        elif op == OP_CHUNK:
+            T, start, want = c[1], c[2], c[3]
+            comm.recv_activations(T)
+            model.hidden_buffer[:T].copy_(comm.h[:T])
+            pos = torch.arange(start, start + T, dtype=torch.int32, device=dev)
+            pre = torch.tensor([start], dtype=torch.int32, device=dev)
+            model.forward_explicit(dummy_tokens[:T], pos, pos, pre, head_from=(T - 1 if want else T))
+            comm.send_activations(model.hidden_buffer[:T])
+            if comm.last and want:
+                row = model.logits_buffer[0]
+                if mask_first_eos and tables["n_eos"]:
+                    _lib.call("umb_mask_eos", row, tables["eos_dev"], tables["n_eos"])
+                _lib.call("umb_argmax_rows", sampled[:1], row, 1, V)
+                comm.return_ids(sampled, 1)
+            n_dev.fill_(start + T)
+        elif op == OP_COMMIT:
+            res, path = comm.share_commit()
+            model.kv_cache.compact(res, path.contiguous(), tables["max_path"])
+            n_dev.copy_(res[3:4])
+
+
+def run_pp_bench(args, wl, dtype, device, rank, world):
+    """bench.py --parallel pp: one request, target layers sharded over the ranks (static 3x4, greedy)."""
+    import json
+    import time
+
+    import __graft_entry__ as ge
+    from .models.config import KNOWN
+    from .models.llama import Llama, pack_mask_bits
+    from .sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from .speculation.static_speculation_engine import StaticSpeculationEngine
+    ge.build()
+    gm = generate_sequoia_tree(3, 4)
+    T, depth_levels = gm["size"], len(gm["roots"])
+    cfg = KNOWN[wl["target"]]
+    lo, hi = split_layers(cfg.num_hidden_layers, world)[rank]
+    stage = Llama(wl["target"], max_length=args.max_length, device=device, dtype=dtype, seed=args.seed)
+    stage.alloc(layer_range=(lo, hi))
+    stage.reserve(max(stage.CHUNK, T))
+    comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.CHUNK, T), depth_levels)
+    if rank != 0:
+        tables = dict(depth=torch.tensor(gm["depth"], dtype=torch.int32, device=device),
+                      mask_bits=pack_mask_bits((torch.tensor(gm["mask"]) == 1).to(device)).contiguous(),
+                      n_dev=torch.zeros(1, dtype=torch.int32, device=device),
+                      eos_dev=torch.tensor(list(cfg.eos_token_id), dtype=torch.int32, device=device),
+                      n_eos=len(cfg.eos_token_id), max_path=depth_levels)
+        tables["mask_words"] = tables["mask_bits"].shape[1]
+        stage_worker(stage, comm, tables)
+        dist.barrier()
+        dist.destroy_process_group()
+        return None
+    eng = PipelinedStaticEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=gm,
+                                max_length=args.max_length, exit_layer=16, seed=args.seed, hip_graph=False,
+                                stage_model=stage, comm=comm)
+    eng.initialize()
+    g = torch.Generator().manual_seed(1234)
+    prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)
+    assert eng._prefill(prompt)
+    for _ in range(args.warmup):
+        eng.step()
+    torch.cuda.synchronize()
+    start = eng.num_nodes
+    t0 = time.time()
+    for _ in range(args.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    tokens = eng.num_nodes - start
+    comm.command(OP_STOP)
+    out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
+           "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
+           "config": {"workload": wl["desc"], "parallelism": f"pp{world}: target layers sharded, RCCL send/recv of [T,H]",
+                      "tree": "3x4", "prompt_len": args.prompt_len}, "accept_len": round(tokens / args.steps, 3)}
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+from .speculation.static_speculation_engine import StaticSpeculationEngine as _Static  # noqa: E402
+
+
+class PipelinedStaticEngine(_Static):
+    """Static engine whose target is a PipelinedTarget (rank 0 of a layer-sharded group)."""
+
+    def __init__(self, *a, stage_model=None, comm=None, **kw):
+        kw["hip_graph"] = False                     # cross-rank hops are launched eagerly
+        super().__init__(*a, **kw)
+        self._stage_model, self._comm = stage_model, comm
+
+    def initialize(self):
+        self._target_model = PipelinedTarget(self._stage_model, self._comm, self)
+        super().initialize()
+
+    def _feed(self, lo, hi):
+        ids = self.tokens[lo:hi]
+        self.draft_model.prefill_tokens(ids, lo, want_logits=False)
+        first = self.target_model.prefill_tokens(ids, lo, want_logits=True)
+        self.tokens[hi:hi + 1] = first
+        self.num_nodes = hi
+        self.n_dev.fill_(hi)
+        self.last_bonus = None
+
+    def _verify_forward(self):
+        ids = self.target_model.verify_tree(self.tokens, self.n_dev, self.depth, self.tree_size, self.mask_bits,
+                                            self.mask_words)
+        self._remote_sampled = ids
+
+    def _iteration_launch(self):
+        from . import _lib
+        self.build_tree()
+        self._verify_forward()
+        if self._comm.world > 1:
+            self.sampled.copy_(self._remote_sampled)
+        else:
+            _lib.call("umb_argmax_rows", self.sampled, self._stage_model.logits_buffer, self.tree_size, self.vocab_size)
+        _lib.call("umb_accept_scan", self.sampled, self.parents, self.tokens, self.n_dev, self.tree_size,
+                  self.eos_dev, len(self.eos_tokens), self.res, self.path)
+        self._comm.command(OP_COMMIT)
+        res, path = self._comm.share_commit(self.res, self.path)
+        self.draft_model.kv_cache.compact(self.res, self.path, self.max_path)
+        self._stage_model.kv_cache.compact(self.res, self.path, self.max_path)
+        self.res_host.copy_(self.res, non_blocking=True)
+
+    def verify(self):
+        raise NotImplementedError("use step() on the pipelined engine")
