@@ -289,10 +289,15 @@ def main():
             kr = kernel_roofline(eng)
             dom = max(kr.values(), key=lambda r: r["bytes"])
             tot_b, tot_us = sum(r["bytes"] for r in kr.values()), sum(r["us"] for r in kr.values())
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm70b_traffic.json")
+            if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
+                with open(pmc) as f:                      # PMC pass is a separate rocprofv3 run (see profiles/README.md)
+                    traffic, tsrc = json.load(f)["gate_up_traffic_bytes"], "profiles/r01_pmc_gemm70b_traffic.json"
             out["roofline"] = {"bound": "hbm", "kernel": f"skinny_gemm_kernel<{'AWQ' if m.config.awq else 'dense'}, TT=1, R={dom['R']}> "
                                                        f"gate_up N={dom['N']} K={dom['K']} T={eng.tree_size}",
                                "achieved": round(dom["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "avg_launch_us": round(dom["us"], 2), "bytes_per_launch": dom["bytes"],
                                "layer_gemms": {k: {"us": round(v["us"], 2), "GBs": round(v["gbs"], 1), "R": v["R"], "S": v["S"]}
                                                for k, v in kr.items()},
