@@ -27,14 +27,16 @@ typedef struct ihipStream_t* umb_stream_t;   /* == hipStream_t */
 
 /* ------------------------------------------------------------------ weights (load time) */
 /* dense W[N][K] row-major (HF layout; umbrella/models/llama_layer.py:25-40) -> MFMA tile order.
- * out: N*K 16-bit elements.  interleave != 0: packed rows (2m, 2m+1) <- source rows (m, N/2 + m), i.e. a fused
- * [gate; up] weight is stored as (gate_m, up_m) pairs so SiLU(gate)*up can be the GEMM epilogue. */
-int umb_repack_dense(void* out, const void* w, int N, int K, int interleave, int dtype, umb_stream_t stream);
+ * out: N*K 16-bit elements.  Row permutation `mode`: 0 none; 1 fused [gate; up] stack, packed rows (2m, 2m+1) <-
+ * source rows (m, N/2 + m) so SiLU(gate)*up can be the GEMM epilogue; 2 fused [q | k | v] stack, inside each of the
+ * first `rope_heads` heads of size D packed rows (2m, 2m+1) <- (m, m + D/2) so rotate-half RoPE is lane-local. */
+int umb_repack_dense(void* out, const void* w, int N, int K, int mode, int D, int rope_heads, int dtype,
+                     umb_stream_t stream);
 /* AutoAWQ GEMM tensors (umbrella/quantization/awq_utils.py:20-27: qweight [K][N/8] i32,
  * qzeros [K/128][N/8] i32, scales [K/128][N] fp16) -> int4 tile order.
  * outw: N*K/2 bytes, meta: (N/16)*(K/128)*64 bytes (16 x {fp16 scale, fp16 zero} per tile). */
 int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
-                   int N, int K, int group, int interleave, umb_stream_t stream);
+                   int N, int K, int group, int mode, int D, int rope_heads, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ linear layers */
 /* split plan for a [N][K] linear: depends on (N, K, format) only, never on T. */
@@ -48,7 +50,25 @@ void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out);
 int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
              int awq, int S, int R, int epi, int dtype, umb_stream_t stream);
 
-/* ------------------------------------------------------------------ fused epilogues */
+/* Fused work around the GEMM.  RMSNorm is split in two: the producer of the residual stream folds the norm WEIGHT
+ * into the activations it hands over (hw = h * w) and leaves per-64-column sums of squares (ssq [T][stride]); the
+ * consumer GEMM multiplies its OUTPUTS by rsqrt(sum(ssq[t])/ssq_dim + eps) (the per-token factor commutes with the
+ * matmul).  epi 3 / 4 with S > 1: every K-split block publishes its fp32 partial tile, the last block to arrive on
+ * the n-group's counter sums the S partials in split order and runs the epilogue (deterministic, no reduce kernel).
+ *   epi 3: [q|k|v] rows (repack mode 2): 1/rms, RoPE at pos[t] (model_utils.py:17-52), q_out[T][Hq][D],
+ *          K/V appended at slot[t] (attn/cache.py:53-65)
+ *   epi 4: h <- round(round(gemm) + h); hw <- h * norm_w (optional); ssq_out[t][n/64] <- sum h^2 (llama.py:104,112) */
+typedef struct UmbGemmFused {
+  const float* ssq_in; int32_t ssq_groups; float ssq_dim; float eps; int32_t pad0;
+  uint32_t* counters;               /* >= N/64 zeroed words, self-resetting */
+  void* h; void* hw; const void* norm_w; float* ssq_out; int32_t ssq_out_stride; int32_t pad1;
+  const int32_t* pos; const int32_t* slot; const void* cosT; const void* sinT;
+  void* q_out; void* k_cache; void* vt_cache; int32_t Hq, Hkv, D, Lmax;
+} UmbGemmFused;
+int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
+                   int awq, int S, int R, int epi, const UmbGemmFused* fx, int dtype, umb_stream_t stream);
+
+/* ------------------------------------------------------------------ stand-alone epilogues (op-level API) */
 /* flashinfer.rmsnorm (umbrella/models/model_utils.py:54-64) */
 int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype, umb_stream_t stream);
 /* h = residual + sum_s partial ; xn = rmsnorm(h)*w   (llama.py:104-106,112-113 + next layer's :87) */
@@ -58,25 +78,32 @@ int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const voi
 int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
  * + KV_Cache.update_kv_cache (umbrella/attn/cache.py:53-65) at slots slot[t].
- * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax] (layer base pointers). */
+ * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax] (layer base pointers).
+ * paired != 0: the q/k rows of the linear were packed as RoPE partner pairs (repack mode 2). */
 int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
                         const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
-                        void* vt_cache, int dtype, umb_stream_t stream);
+                        void* vt_cache, int paired, int dtype, umb_stream_t stream);
 /* F.embedding (llama.py:124) + per-forward position/slot/prefix resolution.
  * explicit mode: tok/pos/slot/prefix given.  tree mode (tokens_all != NULL):
- * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i. */
+ * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i.
+ * table == NULL: indices only (pipeline stage > 0; x already holds the activations).  hw/norm_w/ssq (optional):
+ * hw = x * norm_w and ssq[t][c/64] = sum of x^2, the inputs of the fused layer chain. */
 int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
                    const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
-                   int* pos_out, int* slot_out, int* prefix_out, int dtype, umb_stream_t stream);
+                   int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
+                   int ssq_stride, int dtype, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ attention */
 /* flashinfer.single_prefill_with_kv_cache(custom_mask=...) (umbrella/attn/cache.py:77-85) and
  * StaticKV_Cache.compute_attention (cache.py:169-192).  Keys [0,*prefix_len) are visible to every
  * row; key *prefix_len + b is visible to row t iff bit b of mask_bits[t*mask_words ...] (NULL: b <= t).
- * po: [max_splits][T][Hq][D] fp32, pml: [max_splits][T][Hq][2] fp32 scratch; chunk*max_splits >= Lmax. */
+ * po: [max_splits][T][Hq][D] fp32, pml: [max_splits][T][Hq][2] fp32 scratch; chunk*max_splits >= Lmax.
+ * counters: NULL -> a second kernel merges the key splits; else >= Hkv*64 zeroed words (self-resetting) and the
+ * last-arriving split block merges in-kernel. */
 int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
                   const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T, int Hq,
-                  int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, int dtype, umb_stream_t stream);
+                  int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, uint32_t* counters, int dtype,
+                  umb_stream_t stream);
 
 /* ------------------------------------------------------------------ tree bookkeeping */
 /* target_logits.argmax(-1) (static_speculation_engine.py:307) */
@@ -136,7 +163,13 @@ typedef struct UmbWorkspace {
   float* attn_po;  float* attn_ml;
   int32_t* pos;  int32_t* slot;  int32_t* prefix;
   float* logits;                    /* [Tmax][V] */
-  int32_t Tmax, attn_chunk, attn_splits, pad_;
+  void* hw;                         /* [Tmax][H] residual stream with the next RMSNorm weight folded in */
+  float* ssq;                       /* [Tmax][ssq_stride] per-64-column sums of squares of h (zero padded) */
+  uint32_t* counters;               /* >= max(N)/64 zeroed words for the split-K last-arriver epilogues */
+  uint32_t* attn_counters;          /* >= Hkv*64 zeroed words */
+  int32_t Tmax, attn_chunk, attn_splits, ssq_stride;
+  int32_t fused, pad_;              /* layer schedule: 0 = 9 launches (split-K reduced at kernel boundaries, fastest
+                                       measured on MI355X), 1 = 5 launches (in-kernel last-arriver reduces) */
 } UmbWorkspace;
 
 typedef struct UmbStep {

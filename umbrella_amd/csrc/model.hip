@@ -3,76 +3,118 @@
 //
 // Restates Llama*.inference + layer_compute (umbrella/models/llama.py:75-134, 262-322,
 // 461-502) and the offload loop (llama.py:196-219) as a kernel schedule:
-//   embed+prep -> rmsnorm -> L x [ qkv gemm -> reduce+rope+kv append -> tree attention ->
-//   o gemm -> reduce+residual+norm -> gate/up gemm -> reduce+silu*mul -> down gemm ->
-//   reduce+residual+next norm ] -> lm_head gemm (fp32 logits)
+//   embed+prep -> L x [ qkv gemm(+1/rms, RoPE, KV append) -> tree attention(+split merge) ->
+//   o gemm(+residual, next norm weight folded, sum of squares) -> gate/up gemm(+1/rms, SiLU*up) ->
+//   down gemm(+residual, ...) ] -> lm_head gemm(+1/rms, fp32 logits)          = 5 launches per layer
 #include "../../include/umbrella_hip.h"
 #include "common.h"
 
-extern "C" int umb_gemm(void*, const void*, int, const void*, const void*, int, int, int, int, int, int, int, int, hipStream_t);
-extern "C" int umb_rmsnorm(void*, const void*, const void*, float, int, int, int, hipStream_t);
-extern "C" int umb_reduce_residual_norm(const void*, int, int, int, const void*, void*, void*, const void*, float, int, hipStream_t);
-extern "C" int umb_reduce_silu_mul(const void*, int, int, int, void*, int, hipStream_t);
-extern "C" int umb_reduce_qkv_rope(const void*, int, int, int, int, int, int, const int*, const int*, const void*, const void*, void*, void*, void*, int, hipStream_t);
-extern "C" int umb_embed_prep(void*, const void*, int, int, const int*, const int*, const int*, const int*, const int*, const int*, int, const int*, int*, int*, int*, int, hipStream_t);
-extern "C" int umb_tree_attn(void*, const void*, const void*, const void*, void*, void*, const int*, const void*, int, int, int, int, int, int, int, int, int, float, int, hipStream_t);
-
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-static inline int lin(const UmbLinear& l, const void* x, int ldx, float* out, int T, int dtype, hipStream_t st,
-                      int epi = 0) {
-  return umb_gemm(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, l.S, l.R, epi, dtype, st);
+static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int T, int dtype, hipStream_t st, int epi,
+                      const UmbGemmFused* fx) {
+  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, l.S, l.R, epi, fx, dtype, st);
 }
 
-static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
+// embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h
+static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
   if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
-  // positions / slots / prefix are resolved on every stage; the gather itself only on stage 0
-  if (!s->skip_embed) {
-    CK(umb_embed_prep(ws->h, m->embed, m->H, s->T, s->tokens, s->positions, s->slots, s->prefix_len, s->tokens_all,
-                      s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix, m->dtype, st));
-  } else {
-    // pipeline stage > 0: resolve indices only (table == NULL skips the gather); ws->h holds the incoming activations
-    CK(umb_embed_prep(ws->xn, nullptr, m->H, s->T, s->tokens, s->positions, s->slots, s->prefix_len, s->tokens_all,
-                      s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix, m->dtype, st));
+  if (!ws->fused) {
+    CK(umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
+                      s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
+                      nullptr, nullptr, nullptr, 0, m->dtype, st));
+    return umb_rmsnorm(ws->xn, ws->h, first_norm, m->eps, s->T, m->H, m->dtype, st);
   }
-  return UMB_OK;
+  return umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
+                        s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
+                        ws->hw, first_norm, ws->ssq, ws->ssq_stride, m->dtype, st);
 }
 
-static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
-                 const void* next_norm, hipStream_t st) {
+// Schedule 0 (default): one decoder layer = 9 launches; split-K partials are reduced at kernel boundaries by
+// small epilogue kernels.  Measured faster on MI355X than schedule 1: an in-kernel cross-workgroup hand-off costs
+// as much as a kernel boundary on the 8-XCD part (profiles/README.md), and it serialises a tail onto every GEMM.
+static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                       const void* next_norm, hipStream_t st) {
   const int T = s->T, dt = m->dtype;
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
-  CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st));
+  CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_qkv_rope(ws->partial, ly.qkv.S, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
-                         m->rope_sin, ws->q, kc, vt, dt, st));
+                         m->rope_sin, ws->q, kc, vt, /*paired=*/1, dt, st));
   CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
-                   s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale, dt,
-                   st));
-  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st));
+                   s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                   nullptr, dt, st));
+  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_residual_norm(ws->partial, ly.o.S, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
-  // gate/up rows are interleaved at load time and the GEMM runs unsplit: SiLU(gate)*up is its epilogue
-  if (ly.gu.S != 1) return UMB_EINVAL;
-  CK(lin(ly.gu, ws->xn, m->H, (float*)ws->act, T, dt, st, /*epi=*/2));
-  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st));
+  if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
+  CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
+  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_residual_norm(ws->partial, ly.down.S, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
                               m->eps, dt, st));
   return UMB_OK;
 }
 
+// Schedule 1: one decoder layer = 5 launches.  RMSNorm is split: its weight is folded into the activations by
+// the producer (hw = h * w), its per-token factor is applied to the consumer GEMM's outputs from `ssq`.
+static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                 const void* next_norm, hipStream_t st) {
+  const int T = s->T, dt = m->dtype;
+  const size_t esz = 2;
+  char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  UmbGemmFused fx = {};
+  // 1. qkv GEMM -> (last split block) 1/rms, RoPE at tree positions, q out, K/V appended at their slots
+  fx.ssq_in = ws->ssq; fx.ssq_groups = ws->ssq_stride; fx.ssq_dim = (float)m->H; fx.eps = m->eps;
+  fx.counters = ws->counters;
+  fx.pos = ws->pos; fx.slot = ws->slot; fx.cosT = m->rope_cos; fx.sinT = m->rope_sin;
+  fx.q_out = ws->q; fx.k_cache = kc; fx.vt_cache = vt; fx.Hq = m->Hq; fx.Hkv = m->Hkv; fx.D = m->D; fx.Lmax = m->Lmax;
+  CK(lin(ly.qkv, ws->hw, m->H, ws->partial, T, dt, st, /*EPI_QKV*/3, &fx));
+  // 2. tree attention (+ fused split merge)
+  CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                   s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                   ws->attn_counters, dt, st));
+  // 3. o_proj GEMM -> h += o ; hw = h * norm2_w ; ssq
+  UmbGemmFused fo = {};
+  fo.counters = ws->counters; fo.h = ws->h; fo.hw = ws->hw; fo.norm_w = ly.norm2; fo.ssq_out = ws->ssq;
+  fo.ssq_out_stride = ws->ssq_stride;
+  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, /*EPI_RESID*/4, &fo));
+  // 4. gate/up GEMM (unsplit, interleaved rows) -> act = SiLU(gate/rms) * up/rms
+  UmbGemmFused fg = {};
+  fg.ssq_in = ws->ssq; fg.ssq_groups = ws->ssq_stride; fg.ssq_dim = (float)m->H; fg.eps = m->eps;
+  if (ly.gu.S != 1) return UMB_EINVAL;
+  CK(lin(ly.gu, ws->hw, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, &fg));
+  // 5. down GEMM -> h += d ; hw = h * (next layer's norm1 | final norm) ; ssq
+  UmbGemmFused fd = {};
+  fd.counters = ws->counters; fd.h = ws->h; fd.hw = next_norm ? ws->hw : nullptr; fd.norm_w = next_norm;
+  fd.ssq_out = ws->ssq; fd.ssq_out_stride = ws->ssq_stride;
+  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, /*EPI_RESID*/4, &fd));
+  return UMB_OK;
+}
+
+static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                 const void* next_norm, hipStream_t st) {
+  return ws->fused ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st);
+}
+
 static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
   if (s->head_from >= s->T) return UMB_OK;
   const int rows = s->T - s->head_from;
-  const char* x = (const char*)ws->xn + (size_t)s->head_from * m->H * 2;
-  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*epi=EPI_ROUND*/1);
+  if (!ws->fused) {
+    const char* xn = (const char*)ws->xn + (size_t)s->head_from * m->H * 2;
+    return lin(m->lm_head, xn, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, nullptr);
+  }
+  const char* x = (const char*)ws->hw + (size_t)s->head_from * m->H * 2;
+  UmbGemmFused fh = {};
+  fh.ssq_in = ws->ssq + (size_t)s->head_from * ws->ssq_stride; fh.ssq_groups = ws->ssq_stride;
+  fh.ssq_dim = (float)m->H; fh.eps = m->eps;
+  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, &fh);
 }
 
 extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
   const int lb = s->layer_begin, le = s->layer_end;
   if (lb < 0 || le > m->L || lb >= le) return UMB_EINVAL;
-  CK(prologue(m, ws, s, st));
-  CK(umb_rmsnorm(ws->xn, ws->h, m->layers[lb].norm1, m->eps, s->T, m->H, m->dtype, st));
+  CK(prologue(m, ws, s, m->layers[lb].norm1, st));
   for (int l = lb; l < le; ++l) {
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
     CK(layer(m, ws, s, m->layers[l], l, nn, st));
@@ -116,8 +158,7 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
   advance();
   for (int i = 0; i < 2 && next < le; ++i) { CK(issue_copy(next, issued & 1)); ++issued; ++next; advance(); }
 
-  CK(prologue(m, ws, s, st));
-  CK(umb_rmsnorm(ws->xn, ws->h, m->layers[lb].norm1, m->eps, s->T, m->H, m->dtype, st));
+  CK(prologue(m, ws, s, m->layers[lb].norm1, st));
   for (int l = lb; l < le; ++l) {
     UmbLayer cur = m->layers[l];
     int buf = -1;

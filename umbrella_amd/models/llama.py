@@ -49,20 +49,23 @@ class PackedLinear:
         return _align(N * K * 2), 0
 
     @classmethod
-    def from_dense(cls, w: torch.Tensor, out=None, force_s1=False, interleave=False):
+    def from_dense(cls, w: torch.Tensor, out=None, force_s1=False, interleave=False, rope=None):
         """w [N, K] fp16/bf16 on the GPU (HF row-major).  interleave: w is a fused [gate; up] stack whose
-        rows are stored as (gate_m, up_m) pairs (SiLU*up becomes the GEMM epilogue; implies S == 1)."""
+        rows are stored as (gate_m, up_m) pairs (SiLU*up becomes the GEMM epilogue; implies S == 1).
+        rope=(D, n_rope_heads): w is a fused [q|k|v] stack; inside each q/k head rows are stored as RoPE
+        partner pairs (m, m + D/2) so rotate-half is lane-local in the GEMM epilogue."""
         N, K = w.shape
         assert N % 16 == 0 and K % 128 == 0, (N, K)
         w = w.contiguous()
         buf = out if out is not None else torch.empty(N * K * 2, dtype=torch.uint8, device=w.device)
-        _lib.call("umb_repack_dense", buf, w, N, K, int(interleave), _lib.dtype_code(w.dtype))
+        mode, D, rh = (1, 0, 0) if interleave else ((2, rope[0], rope[1]) if rope else (0, 0, 0))
+        _lib.call("umb_repack_dense", buf, w, N, K, mode, D, rh, _lib.dtype_code(w.dtype))
         lin = cls(N, K, False, buf, None, force_s1 or interleave)
-        lin.interleaved = bool(interleave)
+        lin.interleaved, lin.rope = bool(interleave), rope
         return lin
 
     @classmethod
-    def from_awq(cls, qweight, qzeros, scales, group=128, out_w=None, out_meta=None, interleave=False):
+    def from_awq(cls, qweight, qzeros, scales, group=128, out_w=None, out_meta=None, interleave=False, rope=None):
         """AutoAWQ GEMM tensors on the GPU: qweight [K, N/8] i32, qzeros [K/G, N/8] i32, scales [K/G, N] fp16."""
         K, N = qweight.shape[0], qweight.shape[1] * 8
         assert N % 16 == 0 and K % 128 == 0 and group == 128, (N, K, group)
@@ -70,9 +73,10 @@ class PackedLinear:
         w = out_w if out_w is not None else torch.empty(wb, dtype=torch.uint8, device=qweight.device)
         meta = out_meta if out_meta is not None else torch.empty(mb, dtype=torch.uint8, device=qweight.device)
         _lib.call("umb_awq_repack", w, meta, qweight.contiguous(), qzeros.contiguous(),
-                  scales.to(torch.float16).contiguous(), N, K, group, int(interleave))
+                  scales.to(torch.float16).contiguous(), N, K, group, *((1, 0, 0) if interleave else
+                                                                         ((2, rope[0], rope[1]) if rope else (0, 0, 0))))
         lin = cls(N, K, True, w, meta, force_s1=interleave)
-        lin.interleaved = bool(interleave)
+        lin.interleaved, lin.rope = bool(interleave), rope
         return lin
 
     def struct(self, w_ptr=None, meta_ptr=None) -> UmbLinear:
@@ -125,6 +129,9 @@ class Llama(LLMBase):
         self.max_length = (max_length + 31) // 32 * 32
         self.offload, self.cuda_graph = offload, cuda_graph
         self._state, self._seed = state_dict, seed
+        # layer schedule: False = 9 launches / layer with kernel-boundary split-K reduces (fastest measured),
+        # True = 5 launches / layer with in-kernel last-arriver reduces (see csrc/model.hip)
+        self.fused = os.environ.get("UMB_FUSED", "0") == "1"
         if config is not None:
             self.config = config
         elif os.path.isdir(model_name):
@@ -188,6 +195,7 @@ class Llama(LLMBase):
         N = sum(shapes[n][0] for n in names)
         K = shapes[names[0]][1]
         il = names[0] == "mlp.gate_proj"          # fused [gate; up]: interleave rows, SiLU*up in the GEMM epilogue
+        rope = (c.head_dim, c.num_attention_heads + c.num_key_value_heads) if names[0] == "self_attn.q_proj" else None
         wb, mb = PackedLinear.packed_bytes(N, K, c.awq)
         w_view = slab[cursor:cursor + (N * K // 2 if c.awq else N * K * 2)]
         meta_view = slab[cursor + wb:cursor + wb + (N // 16) * (K // 128) * 64] if c.awq else None
@@ -204,10 +212,10 @@ class Llama(LLMBase):
             qw = torch.cat([p[0] for p in parts], dim=1)
             qz = torch.cat([p[1] for p in parts], dim=1)
             sc = torch.cat([p[2] for p in parts], dim=1)
-            lin = PackedLinear.from_awq(qw, qz, sc, c.awq_group, out_w=w_view, out_meta=meta_view, interleave=il)
+            lin = PackedLinear.from_awq(qw, qz, sc, c.awq_group, out_w=w_view, out_meta=meta_view, interleave=il, rope=rope)
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
-            lin = PackedLinear.from_dense(w, out=w_view, interleave=il)
+            lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
 
@@ -343,11 +351,21 @@ class Llama(LLMBase):
         w["slot"] = torch.zeros(T, dtype=torch.int32, device=dev)
         w["prefix"] = torch.zeros(1, dtype=torch.int32, device=dev)
         w["logits"] = torch.empty(T if self.is_last else 1, V if self.is_last else 8, dtype=torch.float32, device=dev)
+        w["hw"] = torch.zeros(T, H, dtype=dt, device=dev)
+        self.ssq_stride = (H // 64 + 3) // 4 * 4
+        w["ssq"] = torch.zeros(T, self.ssq_stride, dtype=torch.float32, device=dev)
+        maxn = max(N for (N, K, S) in self._plans.values())
+        if not hasattr(self, "_counters"):          # self-resetting arrival counters (zero between launches)
+            self._counters = torch.zeros(maxn // 64 + 64, dtype=torch.int32, device=dev)
+            self._attn_counters = torch.zeros(c.num_key_value_heads * 64 + 64, dtype=torch.int32, device=dev)
         ws = self._ws = UmbWorkspace()
         ws.h, ws.xn, ws.q, ws.attn, ws.act = (w[k].data_ptr() for k in ("h", "xn", "q", "attn", "act"))
         ws.partial, ws.attn_po, ws.attn_ml = w["partial"].data_ptr(), w["po"].data_ptr(), w["ml"].data_ptr()
         ws.pos, ws.slot, ws.prefix, ws.logits = (w[k].data_ptr() for k in ("pos", "slot", "prefix", "logits"))
-        ws.Tmax, ws.attn_chunk, ws.attn_splits = T, self.attn_chunk, self.attn_splits
+        ws.hw, ws.ssq = w["hw"].data_ptr(), w["ssq"].data_ptr()
+        ws.counters, ws.attn_counters = self._counters.data_ptr(), self._attn_counters.data_ptr()
+        ws.Tmax, ws.attn_chunk, ws.attn_splits, ws.ssq_stride = T, self.attn_chunk, self.attn_splits, self.ssq_stride
+        ws.fused = int(self.fused)
 
     @property
     def logits_buffer(self) -> torch.Tensor:
