@@ -23,6 +23,9 @@
 //     (batch-invariant), which is what makes greedy spec == greedy AR exact.
 #include "common.h"
 #include <type_traits>
+#ifndef UMB_CB1
+#define UMB_CB1 4
+#endif
 
 // ------------------------------------------------------------------ repack (load time)
 // packed row n <- source row rowmap(n):
@@ -107,6 +110,14 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
 // awq_ext.dequantize_weights_cuda produces -- via v_pk_add_f16 / v_pk_mul_f16 (fp16 activations only).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+// (a & mask) | magic in ONE VALU op.  gfx9 VOP3 may read a single SGPR/constant, so hipcc splits the pattern into
+// v_and + v_or when both constants live in SGPRs; keeping `magic` in a VGPR makes v_and_or_b32 encodable.
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned magic_v) {
+  unsigned r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(magic_v));
+  return r;
+}
+
 template <typename P, int AWQ, int R> struct Stage {
   u32x4 a[R][AWQ ? 1 : 4];
   u32x4 m4[AWQ == 1 ? R : 1];     // folded path: 4 x {scale, zero} for output rows g*4 .. g*4+3
@@ -155,6 +166,8 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
       const _Float16 nz16 = -((_Float16)64.0f + zf);
       const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
       const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+      unsigned magic = 0x64006400u;
+      asm volatile("" : "+v"(magic));                       // pin the magic constant in a VGPR
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const unsigned w = st.a[r][0][s];
@@ -162,10 +175,10 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
         u32x4 f;
         // nibbles at mantissa bits 0..3 give fp16(1024 + q); at bits 4..7 fp16(1024 + 16 q): one shift per
         // dword instead of three.  (q - z) is exact in fp16 either way, then one rounding in (q - z) * s.
-        const h2 t0 = __builtin_bit_cast(h2, (w & 0x000F000Fu) | 0x64006400u);
-        const h2 t1 = __builtin_bit_cast(h2, (w & 0x00F000F0u) | 0x64006400u);
-        const h2 t2 = __builtin_bit_cast(h2, (w8 & 0x000F000Fu) | 0x64006400u);
-        const h2 t3 = __builtin_bit_cast(h2, (w8 & 0x00F000F0u) | 0x64006400u);
+        const h2 t0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
+        const h2 t1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
+        const h2 t2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
+        const h2 t3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
 #ifdef UMB_EXP_NODEQ
         f[0] = w; f[1] = w8; f[2] = w + 1; f[3] = w8 + 1;
 #else
@@ -551,7 +564,7 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     if (fx.slot) fx.slot += t0;
     if (fx.q_out) fx.q_out += (long)t0 * fx.Hq * fx.D;
     int rc;
-    if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    if (tn <= 16) rc = launch_r<P, AWQ, 1, UMB_CB1>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     if (rc) return rc;
