@@ -24,7 +24,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K", [(512, 256), (3072, 2048), (4096 + 16, 1024), (128256, 256)])
-@pytest.mark.parametrize("T", [1, 5, 13, 16, 17, 33, 64, 70])
+@pytest.mark.parametrize("T", [1, 5, 13, 16, 17, 33, 64, 70, 257, 300])
 def test_gemm_dense(dev, dtype, N, K, T):
     from umbrella_amd.models.llama import PackedLinear
     g = torch.Generator(device="cpu").manual_seed(N + K + T)
@@ -38,7 +38,7 @@ def test_gemm_dense(dev, dtype, N, K, T):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,K", [(512, 256), (1024, 2048), (28672 // 4, 1024)])
-@pytest.mark.parametrize("T", [1, 13, 16, 31, 40, 64, 65])
+@pytest.mark.parametrize("T", [1, 13, 16, 31, 40, 64, 65, 200, 257])
 def test_gemm_awq(dev, dtype, N, K, T):
     from umbrella_amd.models.awq_format import pack_rows
     from umbrella_amd.models.llama import PackedLinear
@@ -297,7 +297,7 @@ def test_kv_compaction(dev, D):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("awq", [False, True])
-@pytest.mark.parametrize("T", [1, 13, 40])
+@pytest.mark.parametrize("T", [1, 13, 40, 130])
 def test_gemm_fused_silu_epilogue(dev, dtype, awq, T):
     """[gate; up] stored as interleaved rows: SiLU(gate)*up is the GEMM epilogue (umbrella/models/llama.py:107-110)."""
     from umbrella_amd.models.awq_format import pack_rows

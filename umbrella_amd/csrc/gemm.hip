@@ -146,57 +146,20 @@ __device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const u32x4* __
   }
 }
 
-// xf: LDS fragments of this 128-k block, index (tt*4 + s)*64 + lane
+// xf: LDS fragments of this 128-k block, index (tt*4 + s)*64 + lane.
+// The weight fragments are built once per 128-k block (dequant for int4), then applied to every token tile:
+// at TT = 16 (256 tokens per launch, the multi-token verify) that is 64 MFMAs per KiB of weights -> matrix-pipe
+// bound, the weights are read once per 256 tokens.
 template <typename P, int AWQ, int TT, int R>
 __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const u32x4* xf, int lane,
                                               f32x4 (&acc)[R][TT]) {
-  u32x4 b[TT][4];
+  if (AWQ == 1) {
+    // folded dequant (any activation dtype): needs per-token sums, small TT only
+    u32x4 b[TT][4];
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt)
+    for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
-  if (AWQ == 2) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const unsigned mm = st.m1[r];
-      const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
-      const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
-      const h2 s2 = {sc, sc};
-      const _Float16 nz = -((_Float16)1024.0f + zf);          // exact: |1024 + z| <= 1039
-      const _Float16 nz16 = -((_Float16)64.0f + zf);
-      const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
-      const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
-      unsigned magic = 0x64006400u;
-      asm volatile("" : "+v"(magic));                       // pin the magic constant in a VGPR
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned w = st.a[r][0][s];
-        const unsigned w8 = w >> 8;
-        u32x4 f;
-        // nibbles at mantissa bits 0..3 give fp16(1024 + q); at bits 4..7 fp16(1024 + 16 q): one shift per
-        // dword instead of three.  (q - z) is exact in fp16 either way, then one rounding in (q - z) * s.
-        const h2 t0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
-        const h2 t1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
-        const h2 t2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
-        const h2 t3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
-#ifdef UMB_EXP_NODEQ
-        f[0] = w; f[1] = w8; f[2] = w + 1; f[3] = w8 + 1;
-#else
-        f[0] = __builtin_bit_cast(unsigned, (t0 + nz2) * s2);
-        f[1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t1, sixteenth, nz16_2) * s2);
-        f[2] = __builtin_bit_cast(unsigned, (t2 + nz2) * s2);
-        f[3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t3, sixteenth, nz16_2) * s2);
-#endif
-#ifdef UMB_EXP_NOMFMA
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) { acc[r][tt][0] += __uint_as_float(f[0] ^ b[tt][s][0]); acc[r][tt][1] += __uint_as_float(f[1] ^ f[2] ^ f[3]); }
-#else
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[r][tt] = P::mfma(f, b[tt][s], acc[r][tt]);
-#endif
-      }
-    }
-  } else if (AWQ == 1) {
+      for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
     const u32x4 ones = {P::ONE2, P::ONE2, P::ONE2, P::ONE2};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[TT];
@@ -235,13 +198,53 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
         for (int e = 0; e < 4; ++e) acc[r][tt][e] += sc[e] * (ga[tt][e] - zo[e] * sx);
       }
     }
-  } else {
+    return;
+  }
+  // ---- weight fragments wf[r][s]
+  u32x4 wf[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (AWQ == 2) {
+      const unsigned mm = st.m1[r];
+      const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
+      const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
+      const h2 s2 = {sc, sc};
+      const _Float16 nz = -((_Float16)1024.0f + zf);          // exact: |1024 + z| <= 1039
+      const _Float16 nz16 = -((_Float16)64.0f + zf);
+      const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
+      const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+      unsigned magic = 0x64006400u;
+      asm volatile("" : "+v"(magic));                       // pin the magic constant in a VGPR
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned w = st.a[r][0][s];
+        const unsigned w8 = w >> 8;
+        // nibbles at mantissa bits 0..3 give fp16(1024 + q); at bits 4..7 fp16(1024 + 16 q): one shift per
+        // dword instead of three.  (q - z) is exact in fp16 either way, then one rounding in (q - z) * s.
+        const h2 t0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
+        const h2 t1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
+        const h2 t2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
+        const h2 t3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
+        wf[r][s][0] = __builtin_bit_cast(unsigned, (t0 + nz2) * s2);
+        wf[r][s][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t1, sixteenth, nz16_2) * s2);
+        wf[r][s][2] = __builtin_bit_cast(unsigned, (t2 + nz2) * s2);
+        wf[r][s][3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(t3, sixteenth, nz16_2) * s2);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wf[r][s] = st.a[r][s];
+    }
+  }
+  // ---- token tiles: 4 conflict-free ds_read_b128 + 4 R MFMAs each
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    u32x4 b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = xf[(tt * 4 + s) * 64 + lane];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[r][tt] = P::mfma(st.a[r][s], b[tt][s], acc[r][tt]);
+      for (int r = 0; r < R; ++r) acc[r][tt] = P::mfma(wf[r][s], b[s], acc[r][tt]);
   }
 }
 
@@ -531,6 +534,14 @@ static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, flo
   const int NT = N / 16;
   const int nblk = (NT + 4 * R - 1) / (4 * R);
   size_t smem = (size_t)2 * CB * TT * 4 * 1024;
+  if (smem > 64 * 1024) {
+    static bool once = false;      // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
+    if (!once) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<P, AWQ, TT, R, CB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return UMB_EHIP;
+      once = true;
+    }
+  }
   hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB>), dim3((unsigned)(nblk * S)), dim3(256), smem, st,
                      (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, fx);
   UMB_LAUNCH_CHECK();
@@ -551,8 +562,13 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
                      int S, int epi, const GemmFused& fx0, hipStream_t st) {
   // tokens beyond 64 go through further launches (weights re-read from L2/HBM)
   const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
-  for (int t0 = 0; t0 < T; t0 += 64) {
-    const int tn = min(64, T - t0);
+  // token chunking: 64 per launch.  A 256-token variant of this kernel (TT = 16, one n-tile per wave) was measured
+  // SLOWER per token (1600 vs 4 x 314 us per 70B layer): every MFMA pulls its 1 KiB B fragment from LDS, which
+  // pins the matrix pipe to the LDS rate with one wave per SIMD.  The large-T verify needs a register-tiled
+  // (R x TT per wave) kernel -- next round; until then weights are re-read once per 64 tokens.
+  const int step = 64;
+  for (int t0 = 0; t0 < T; t0 += step) {
+    const int tn = min(step, T - t0);
     const u16* xx = x + (long)t0 * ldx;
     float* oo = out + (long)t0 * ostride;      // out is [S][T][N] over the full T; split stride stays T
     GemmFused fx = fx0;                        // per-chunk views of the token-indexed side buffers
