@@ -124,24 +124,48 @@ template <typename P, int AWQ, int R> struct Stage {
   unsigned m1[AWQ == 2 ? R : 1];  // exact path : {scale, zero} of this lane's weight row
 };
 
+// Wave-uniform base pointers of one wave's weight stream (kept in SGPRs): the loads then use the
+// saddr + 32-bit lane offset form and need no per-load 64-bit VALU address arithmetic.
+template <int AWQ, int R> struct WaveBase {
+  const u32x4* w[R];              // tile stream of n-tile r at k-block 0
+  const unsigned char* m[R];      // AWQ metadata stream
+  long wstep, mstep;              // per 128-k block, in elements of the pointer type
+};
+
+template <int AWQ, int R>
+__device__ __forceinline__ WaveBase<AWQ, R> wave_base(const u32x4* wp, const unsigned char* meta, int nt0, int KB) {
+  WaveBase<AWQ, R> b;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int nt = nt0 + r;
+    if (AWQ) {
+      const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);       // tile order [N/64][K/128][4]
+      b.w[r] = wp + tile0 * 64;
+      b.m[r] = meta + tile0 * 64;
+    } else {
+      b.w[r] = wp + ((long)nt * KB) * 256;                             // 4 tiles (128 k) contiguous per k-block
+      b.m[r] = nullptr;
+    }
+  }
+  b.wstep = AWQ ? 4 * 64 : 256;
+  b.mstep = 4 * 64;
+  return b;
+}
+
 template <typename P, int AWQ, int R>
-__device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const u32x4* __restrict__ wp,
-                                           const unsigned char* __restrict__ meta, int nt0, int KB, int kb,
-                                           int lane) {
+__device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const WaveBase<AWQ, R>& wb, int kb, int lane) {
   const int g = lane >> 4, i = lane & 15;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
+    const u32x4* w = wb.w[r] + (long)kb * wb.wstep;                    // uniform
     if (AWQ) {
-      const int nt = nt0 + r;
-      const long tile = ((long)(nt >> 2) * KB + kb) * 4 + (nt & 3);
-      st.a[r][0] = __builtin_nontemporal_load(wp + tile * 64 + lane);
-      const unsigned char* m = meta + tile * 64;
+      st.a[r][0] = __builtin_nontemporal_load(w + lane);
+      const unsigned char* m = wb.m[r] + (long)kb * wb.mstep;          // uniform
       if (AWQ == 1) st.m4[r] = *reinterpret_cast<const u32x4*>(m + g * 16);
       else st.m1[r] = *reinterpret_cast<const unsigned*>(m + i * 4);
     } else {
-      const u32x4* p = wp + ((long)(nt0 + r) * KB + kb) * 256 + lane;   // 4 tiles (128 k) contiguous
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st.a[r][s] = __builtin_nontemporal_load(p + s * 64);
+      for (int s = 0; s < 4; ++s) st.a[r][s] = __builtin_nontemporal_load(w + s * 64 + lane);
     }
   }
 }
@@ -295,33 +319,62 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[r][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const WaveBase<AWQ, R> wb = wave_base<AWQ, R>(wp, meta, active ? nt0 : 0, KB);
+  const int nkb = kb1 - kb0;
+  constexpr int PF = 2 * CB;                 // ring of PF weight stages: PF x R KiB-tiles in flight per wave
+  // FULL: the slab is a whole number of rings and every wave owns tiles -> no per-k-block predicates at all
+  const bool full = (nkb % PF == 0) && (NT % (4 * R) == 0) && nkb > 0;
+
   u32x4 xr[FPW];
-  auto load_x = [&](int c) {
+  Stage<P, AWQ, R> st[PF];
+  auto run = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    auto load_x = [&](int c) {
+      const u16* xb = x + (long)(kb0 + c * CB) * 128;                  // uniform
 #pragma unroll
-    for (int i = 0; i < FPW; ++i) {
-      const int f = i * 4 + wv;
-      const int kb = kb0 + c * CB + f / (TT * 4);
-      const int tok = ((f >> 2) % TT) * 16 + j;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      xr[i] = (tok < T && kb < kb1)
-                  ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + kb * 128 + (f & 3) * 32 + g * 8) : z;
+      for (int i = 0; i < FPW; ++i) {
+        const int f = i * 4 + wv;
+        const int kl = f / (TT * 4);
+        const int tok = ((f >> 2) % TT) * 16 + j;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const bool ok = tok < T && (FULL || kb0 + c * CB + kl < kb1);
+        xr[i] = ok ? *reinterpret_cast<const u32x4*>(xb + (long)tok * ldx + kl * 128 + (f & 3) * 32 + g * 8) : z;
+      }
+    };
+    auto store_x = [&](int c) {
+#pragma unroll
+      for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
+    };
+    load_x(0);
+    if (FULL || active) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        if (FULL || kb0 + i < kb1) stage_load<P, AWQ, R>(st[i], wb, kb0 + i, lane);
+    }
+    auto chunk = [&](int c, auto half) {
+      constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
+      store_x(c);
+      __syncthreads();
+      if (c + 1 < nchunks) load_x(c + 1);
+      if (FULL || active) {
+        const u32x4* xc = xs + (c & 1) * F * 64;
+        const bool more = (c + 2) * CB < nkb;             // FULL: one uniform refill decision per chunk
+#pragma unroll
+        for (int kl = 0; kl < CB; ++kl) {
+          const int kb = kb0 + c * CB + kl;
+          if (FULL || kb < kb1) {
+            stage_compute<P, AWQ, TT, R>(st[H * CB + kl], xc + kl * TT * 4 * 64, lane, acc);
+            if (FULL ? more : (kb + PF < kb1)) stage_load<P, AWQ, R>(st[H * CB + kl], wb, kb + PF, lane);
+          }
+        }
+      }
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk(c, std::integral_constant<int, 0>{});
+      if (FULL || c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
     }
   };
-  auto store_x = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
-  };
-
-  // ring of PF = 2*CB weight stages: PF x R tiles of 1 KiB loads in flight per wave
-  constexpr int PF = 2 * CB;
-  Stage<P, AWQ, R> st[PF];
-  load_x(0);
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i)
-      if (kb0 + i < kb1) stage_load<P, AWQ, R>(st[i], wp, meta, nt0, KB, kb0 + i, lane);
-  }
-  // per-token 1/rms of the producer's residual stream (its loads overlap the weight prefetch)
+  // per-token 1/rms of the producer's residual stream (its loads overlap the weight stream)
   float inv[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -337,27 +390,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
       inv[tt] = rsqrtf(a / fx.ssq_dim + fx.eps);
     }
   }
-  auto chunk = [&](int c, auto half) {
-    constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
-    store_x(c);
-    __syncthreads();
-    if (c + 1 < nchunks) load_x(c + 1);
-    if (active) {
-      const u32x4* xc = xs + (c & 1) * F * 64;
-#pragma unroll
-      for (int kl = 0; kl < CB; ++kl) {
-        const int kb = kb0 + c * CB + kl;
-        if (kb < kb1) {
-          stage_compute<P, AWQ, TT, R>(st[H * CB + kl], xc + kl * TT * 4 * 64, lane, acc);
-          if (kb + PF < kb1) stage_load<P, AWQ, R>(st[H * CB + kl], wp, meta, nt0, KB, kb + PF, lane);
-        }
-      }
-    }
-  };
-  for (int c = 0; c < nchunks; c += 2) {
-    chunk(c, std::integral_constant<int, 0>{});
-    if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
-  }
+  if (full) run(std::true_type{});
+  else run(std::false_type{});
 
   // ------------------------------------------------------------------ direct epilogues (no cross-block step)
   if (epi <= EPI_SILU) {
@@ -514,11 +548,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out) {
   const int NT = N / 16, KB = K / 128;
   int R = 1;
-  if (!awq && NT % 2 == 0 && NT >= 4096) R = 2;   // int4 tile order is tied to R == 1 (4 n-tiles per block)
+  if (!awq && NT % 2 == 0 && NT >= 4096) R = 2;
+  if (awq && NT % 8 == 0 && NT >= 512) R = 2;      // two independent dequant chains per wave: +6-8 % measured
   int S = 1;
   if (!force_s1) {
     const int nblk = (NT + 4 * R - 1) / (4 * R);
-    S = (1024 + nblk - 1) / nblk;                            // aim at ~1024 blocks (16 waves / CU)
+    S = (1024 / R + nblk - 1) / nblk;                        // aim at ~4096 n-tile streams (16 / CU)
     const int min_blocks = awq ? 4 : 2;                       // keep >= 512 / 256 k per slab
     if (S > KB / min_blocks) S = KB / min_blocks;
     if (S > 16) S = 16;
@@ -603,7 +638,7 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
                               int K, int awq, int S, int R, int epi, const UmbGemmFusedC* fxc, int dtype,
                               hipStream_t st) {
   if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 4 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
-  if (awq && (N % 64 || R != 1)) return UMB_EINVAL;
+  if (awq && (N % 64 || (R != 1 && (N / 16) % (4 * R)))) return UMB_EINVAL;
   GemmFused fx = {};
   if (fxc) {
     fx.ssq_in = fxc->ssq_in; fx.ssq_groups = fxc->ssq_groups; fx.ssq_dim = fxc->ssq_dim; fx.eps = fxc->eps;

@@ -216,8 +216,8 @@ class Llama(LLMBase):
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
             lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
-        if self.fused and os.environ.get("UMB_FUSED_S1", "0") == "1":      # experiment: unsplit GEMMs, direct epilogues
-            lin.S = 1
+        if self.fused:
+            lin.R = 1                              # the in-kernel split epilogues own one n-tile per wave
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
 
