@@ -302,7 +302,7 @@ def main():
                                "layer_gemms": {k: {"us": round(v["us"], 2), "GBs": round(v["gbs"], 1), "R": v["R"], "S": v["S"]}
                                                for k, v in kr.items()},
                                "layer_gemms_GBs": round(tot_b / tot_us / 1e3, 1)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, gm, accept_len, torch.get_num_threads())
             except Exception as e:                                        # never lose the GPU line to the baseline leg
