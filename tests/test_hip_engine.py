@@ -294,3 +294,55 @@ def test_fused_layer_schedule(dev, awq, monkeypatch):
     out = eng.generate(input_ids=PROMPT, max_new_tokens=32)
     check_greedy(G, sd, PROMPT, out["generated_tokens"], dtype, tol=0.12)
     assert out["avg_accept_tokens"] > 2.5
+
+
+def test_full_size_1b_shapes_greedy_property(dev):
+    """BASELINE config 1 shapes at full size (Llama-3.2-1B target + itself as draft, random-init weights):
+    size-independent properties instead of golden vectors -- (1) hipGraph replay is bit-identical to eager,
+    (2) every emitted token is an arg-max of the fp32 CPU oracle on the same weights within the stated logit
+    tolerance, (3) self-draft acceptance is far above 1 (the tree is really verified, not just the bonus token)."""
+    import copy
+    from oracle.model import OracleLlama
+    from umbrella_amd.models.config import KNOWN, rope_inv_freq
+    from umbrella_amd.models.llama import Llama
+    from umbrella_amd.models.synthetic import linear_shapes
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    name, dtype = "meta-llama/Llama-3.2-1B-Instruct", torch.float16
+    cfg = copy.copy(KNOWN[name])
+    cfg.num_hidden_layers = 4                       # depth is irrelevant to the properties; keeps the CPU oracle short
+    g = torch.Generator().manual_seed(7)
+    sd = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, cfg.hidden_size, generator=g) * 0.05,
+          "model.norm.weight": torch.ones(cfg.hidden_size)}
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for ln, (n, k) in linear_shapes(cfg).items():
+            sd[p + ln + ".weight"] = torch.randn(n, k, generator=g) * 0.02
+        sd[p + "input_layernorm.weight"] = torch.ones(cfg.hidden_size)
+        sd[p + "post_attention_layernorm.weight"] = torch.ones(cfg.hidden_size)
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    outs = []
+    for graph in (True, False):
+        t = Llama(name, max_length=512, device=str(dev), dtype=dtype, state_dict=sd, config=cfg); t.alloc()
+        d = Llama(name, max_length=512, device=str(dev), dtype=dtype, state_dict=sd, config=cfg, cuda_graph=True); d.alloc()
+        eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap=generate_sequoia_tree(3, 4),
+                                      max_length=512, draft_model_obj=d, target_model_obj=t, tokenizer=IdTokenizer(),
+                                      hip_graph=graph)
+        eng.initialize()
+        gp = torch.Generator().manual_seed(1)
+        prompt = torch.randint(3, 128000, (96,), generator=gp).tolist()
+        outs.append(eng.generate(input_ids=prompt, max_new_tokens=24))
+        del eng, t, d
+    assert outs[0]["generated_tokens"] == outs[1]["generated_tokens"]
+    assert outs[0]["avg_accept_tokens"] > 2.5
+    toks = outs[0]["generated_tokens"]
+    inv, sc = rope_inv_freq(cfg)
+    o = OracleLlama(cfg, {k: v.float() for k, v in sd.items()}, inv, sc, max_length=160, dtype=torch.float32)
+    seq = prompt + toks
+    n = len(seq)
+    logits = o.inference(torch.tensor([seq]), torch.arange(n)[None], torch.tril(torch.ones(n, 160, dtype=torch.bool)),
+                         torch.arange(n))[0]
+    for i, tok in enumerate(toks):
+        row = logits[len(prompt) + i - 1]
+        assert float(row.max() - row[tok]) <= 0.06, (i, tok, float(row.max() - row[tok]))

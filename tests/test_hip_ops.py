@@ -412,3 +412,27 @@ def test_gemm_fused_qkv_epilogue(dev, dtype, T, awq):
     vg = vt.cpu()[:, :, slot.long()].permute(2, 0, 1)
     assert (vg.float() - vr.float()).abs().max() <= tol * vr.float().abs().max()
     assert int(counters.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("N,K", [(57344, 8192), (8192, 28672), (10240, 8192)])
+def test_gemm_awq_full_size_properties(dev, N, K):
+    """Llama-70B AWQ linear shapes at full size (BASELINE configs 3-5): size-independent properties --
+    batch invariance (bitwise), linearity, zero in -> zero out -- plus the CPU oracle on column slices."""
+    from umbrella_amd.models.llama import PackedLinear
+    from umbrella_amd.models.synthetic import synth_awq_tensors
+    gen = torch.Generator(device=dev).manual_seed(N + K)
+    qw, qz, sc = synth_awq_tensors(N, K, 128, dev, gen)
+    lin = PackedLinear.from_awq(qw, qz, sc)
+    x = (torch.randn(13, K, device=dev, generator=gen) * 0.5).half()
+    y = lin.apply(x)
+    assert torch.equal(lin.apply(x[:1].contiguous()), y[:1]) and torch.equal(lin.apply(x[:5].contiguous()), y[:5])
+    assert float(lin.apply(torch.zeros_like(x)).abs().max()) == 0.0
+    x2 = (torch.randn(13, K, device=dev, generator=gen) * 0.5).half()
+    ysum = lin.apply((x.float() + x2.float()).half())
+    lin_err = (ysum - (y + lin.apply(x2))).abs().max() / y.abs().max()
+    assert float(lin_err) < 5e-3, float(lin_err)                      # fp16 rounding of x1 + x2 only
+    for c0 in (0, N // 2 + 64, N - 64):
+        ref = O.awq_linear(x.cpu().float(), qw[:, c0 // 8:(c0 + 64) // 8].cpu(), qz[:, c0 // 8:(c0 + 64) // 8].cpu(),
+                           sc[:, c0:c0 + 64].cpu(), 128)
+        got = y[:, c0:c0 + 64].cpu()
+        assert _rel(got, ref) < 2e-3, (c0, _rel(got, ref))
