@@ -91,16 +91,34 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
       float pv[8];
       float tmax = NEG_BIG;
       const bool need_mask = (k0 + 32 > prefix);
+      // this lane's 8 keys are contiguous: bit b = key - prefix of mask row t; they span at most two 64-bit words,
+      // fetched once per tile (the per-key loads serialised into ~1 us round trips each on wide trees)
+      const int bfirst = k0 + gq * 8 - prefix;
+      unsigned vbits = 0xffu;                                   // bit e: key e of this lane is visible
+      if (need_mask) {
+        if (mask_bits) {
+          const int lo = max(bfirst, 0), wi = lo >> 6;
+          const unsigned long long* mrow = mask_bits + (long)t * mask_words;
+          const unsigned long long w0 = mrow[min(wi, mask_words - 1)], w1 = mrow[min(wi + 1, mask_words - 1)];
+          vbits = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int b = bfirst + e;
+            unsigned v = 1u;                                    // keys before the prefix boundary are visible
+            if (b >= 0) v = (unsigned)((((b >> 6) == wi ? w0 : w1) >> (b & 63)) & 1ull);
+            vbits |= v << e;
+          }
+        } else {
+          vbits = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vbits |= (unsigned)(bfirst + e <= t) << e;      // causal: b <= t
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int key = k0 + gq * 8 + e;
         float sc = st[e >> 2][e & 3] * scale;
-        bool vis = row_ok && key < k_hi;
-        if (need_mask && vis && key >= prefix) {
-          const int b = key - prefix;
-          if (mask_bits) vis = (mask_bits[(long)t * mask_words + (b >> 6)] >> (b & 63)) & 1ull;
-          else vis = b <= t;
-        }
+        const bool vis = row_ok && key < k_hi && ((vbits >> e) & 1u);
         sc = vis ? sc : -INFINITY;
         pv[e] = sc;
         tmax = fmaxf(tmax, sc);

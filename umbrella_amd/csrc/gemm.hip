@@ -23,6 +23,7 @@
 //     (batch-invariant), which is what makes greedy spec == greedy AR exact.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 #ifndef UMB_CB1
 #define UMB_CB1 4
 #endif
@@ -542,6 +543,177 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   }
 }
 
+// ------------------------------------------------------------------ verify GEMM (T > 64): matrix-pipe bound
+// The multi-token verify of the dynamic (SpecExec) trees, T = 257 ... 769, is a true dense contraction: every
+// weight is used by >= 257 tokens.  Block = 128 output rows x 128 tokens, 4 waves as 2 (rows) x 2 (tokens), each
+// wave a 64 x 64 register tile = 4 x 4 MFMA 16x16x32 accumulators, so every LDS fragment read feeds 4 MFMAs
+// (32 MFMAs per 16 ds_read_b128 per 64-k step).  Weight tiles are dequantised ONCE per block per step (wave w
+// unpacks n-tiles 2w, 2w+1) and shared through LDS in fragment order; activations are staged the same way; both
+// double buffered, one barrier per step.  Weights are streamed once per 128 tokens (later token chunks hit the
+// 256 MB Infinity Cache: a 70B linear is 33-235 MB).
+template <typename P, int AWQ>
+__global__ __launch_bounds__(256) void verify_gemm_kernel(const u32x4* __restrict__ wp,
+                                                          const unsigned char* __restrict__ meta,
+                                                          const u16* __restrict__ x, int ldx, float* __restrict__ out,
+                                                          int T, int Tv, int N, int K, int S, int epi, GemmFused fx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* sA = reinterpret_cast<u32x4*>(smem);                        // [2 buf][8 nt][2 s][64]
+  u32x4* sB = sA + 2 * 8 * 2 * 64;                                   // [2 buf][8 tt][2 s][64]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wv >> 1, wt = wv & 1;                               // wave position in the 2 x 2 grid
+  const int j = lane & 15, g = lane >> 4;
+  const int nblk = N / 128;
+  const int nchunk = (Tv + 127) / 128;                               // Tv: tokens handled here (T: row stride of out)
+  const int nb = blockIdx.x % nblk;
+  const int tc = (blockIdx.x / nblk) % nchunk;
+  const int sp = blockIdx.x / (nblk * nchunk);
+  const int KB = K / 128;
+  const int per = (KB + S - 1) / S;
+  const int ks0 = 2 * sp * per, ks1 = 2 * min(KB, sp * per + per);   // 64-k steps
+  const int t0 = tc * 128;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave stages n-tiles nb*8 + 2*wv + {0,1} and activation fragments 4*wv .. 4*wv+3 of each step
+  const u32x4* wbase[2];
+  const unsigned char* mbase[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int nt = nb * 8 + 2 * wv + q;
+    wbase[q] = AWQ ? wp + (((long)(nt >> 2) * KB) * 4 + (nt & 3)) * 64 : wp + ((long)nt * KB) * 256;
+    mbase[q] = AWQ ? meta + (((long)(nt >> 2) * KB) * 4 + (nt & 3)) * 64 : nullptr;
+  }
+  u32x4 ra[2][AWQ ? 1 : 2];   // staged weights per n-tile: dense 2 tiles; AWQ {dword, dword, meta, -}
+  u32x4 rb[4];                // staged activation fragments
+  auto gload = [&](int ks) {
+    const int kb = ks >> 1, hf = ks & 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (AWQ) {
+        const unsigned* tile = reinterpret_cast<const unsigned*>(wbase[q] + (long)kb * 256 + lane);
+        const uint2 w2 = *reinterpret_cast<const uint2*>(tile + hf * 2);
+        ra[q][0][0] = w2.x; ra[q][0][1] = w2.y;
+        ra[q][0][2] = *reinterpret_cast<const unsigned*>(mbase[q] + (long)kb * 256 + (lane & 15) * 4);
+      } else {
+        const u32x4* tile = wbase[q] + (long)kb * 256 + hf * 128 + lane;
+        ra[q][0] = __builtin_nontemporal_load(tile);
+        ra[q][AWQ ? 0 : 1] = __builtin_nontemporal_load(tile + 64);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = wv * 4 + i, tt = f >> 1, sx = f & 1;
+      const int tok = t0 + tt * 16 + j;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rb[i] = (tok < Tv) ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + ks * 64 + sx * 32 + g * 8) : z;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      u32x4 f0, f1;
+      if (AWQ) {
+        const unsigned mm = ra[q][0][2];
+        const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
+        const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
+        const h2 s2 = {sc, sc};
+        const _Float16 nz = -((_Float16)1024.0f + zf), nz16 = -((_Float16)64.0f + zf);
+        const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
+        const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+        unsigned magic = 0x64006400u;
+        asm volatile("" : "+v"(magic));
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const unsigned w = ra[q][0][sx], w8 = w >> 8;
+          const h2 q0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
+          const h2 q1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
+          const h2 q2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
+          const h2 q3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
+          u32x4& f = sx ? f1 : f0;
+          f[0] = __builtin_bit_cast(unsigned, (q0 + nz2) * s2);
+          f[1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q1, sixteenth, nz16_2) * s2);
+          f[2] = __builtin_bit_cast(unsigned, (q2 + nz2) * s2);
+          f[3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q3, sixteenth, nz16_2) * s2);
+        }
+      } else {
+        f0 = ra[q][0]; f1 = ra[q][AWQ ? 0 : 1];
+      }
+      sA[((buf * 8 + 2 * wv + q) * 2 + 0) * 64 + lane] = f0;
+      sA[((buf * 8 + 2 * wv + q) * 2 + 1) * 64 + lane] = f1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sB[(buf * 16 + wv * 4 + i) * 64 + lane] = rb[i];
+  };
+
+  if (ks0 < ks1) {
+    gload(ks0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int buf = (ks - ks0) & 1;
+    if (ks + 1 < ks1) gload(ks + 1);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      u32x4 a[4], b[4];
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) a[n4] = sA[((buf * 8 + wn * 4 + n4) * 2 + sx) * 64 + lane];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) b[t4] = sB[(buf * 16 + (wt * 4 + t4) * 2 + sx) * 64 + lane];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) acc[n4][t4] = P::mfma(a[n4], b[t4], acc[n4][t4]);
+    }
+    if (ks + 1 < ks1) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t4 = 0; t4 < 4; ++t4) {
+    const int tok = t0 + (wt * 4 + t4) * 16 + j;
+    if (tok >= Tv) continue;
+    float inv = 1.f;
+    if (fx.ssq_in) {                                                 // per-token 1/rms (fused RMSNorm consumers only)
+      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      float a = 0.f;
+      for (int q = 0; q < fx.ssq_groups; q += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q); a += v[0]; a += v[1]; a += v[2]; a += v[3]; }
+      inv = rsqrtf(a / fx.ssq_dim + fx.eps);
+    }
+#pragma unroll
+    for (int n4 = 0; n4 < 4; ++n4) {
+      f32x4 v = acc[n4][t4];
+      const int ntile = nb * 8 + wn * 4 + n4;
+      if (epi == EPI_SILU) {
+        v *= inv;
+        const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
+        const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
+        u16* act = reinterpret_cast<u16*>(out);
+        *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + ntile * 8 + g * 2) = pack2<P>(a0, a1);
+      } else {
+        if (epi == EPI_ROUND) { v *= inv; v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
+        *reinterpret_cast<f32x4*>(out + ((long)sp * T + tok) * N + ntile * 16 + g * 4) = v;
+      }
+    }
+  }
+}
+
+template <typename P, int AWQ>
+static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Tv, int N,
+                         int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
+  const size_t smem = (size_t)(2 * 8 * 2 + 2 * 8 * 2) * 64 * 16;     // 64 KiB
+  const int nchunk = (Tv + 127) / 128;
+  hipLaunchKernelGGL((verify_gemm_kernel<P, AWQ>), dim3((unsigned)((N / 128) * nchunk * S)), dim3(256), smem, st,
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv, N, K, S, epi, fx);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
 // ------------------------------------------------------------------ host side
 // (R, S) depend on (N, K, format) only -- never on T -- so a token's result is
 // independent of how many other tokens share the launch.
@@ -597,12 +769,21 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
                      int S, int epi, const GemmFused& fx0, hipStream_t st) {
   // tokens beyond 64 go through further launches (weights re-read from L2/HBM)
   const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
+  int tdone = 0;
+  if constexpr (AWQ != 1) {
+    if (T > 64 && N % 128 == 0 && epi <= EPI_SILU && getenv("UMB_NO_VGEMM") == nullptr) {
+      const int rem = T % 128;
+      tdone = (rem == 0 || rem > 64) ? T : T - rem;                  // a tail of <= 64 tokens is HBM-bound: skinny kernel
+      const int rc = launch_verify<P, AWQ>(wp, meta, x, ldx, out, T, tdone, N, K, S, epi, fx0, st);
+      if (rc || tdone == T) return rc;
+    }
+  }
   // token chunking: 64 per launch.  A 256-token variant of this kernel (TT = 16, one n-tile per wave) was measured
   // SLOWER per token (1600 vs 4 x 314 us per 70B layer): every MFMA pulls its 1 KiB B fragment from LDS, which
   // pins the matrix pipe to the LDS rate with one wave per SIMD.  The large-T verify needs a register-tiled
   // (R x TT per wave) kernel -- next round; until then weights are re-read once per 64 tokens.
   const int step = 64;
-  for (int t0 = 0; t0 < T; t0 += step) {
+  for (int t0 = tdone; t0 < T; t0 += step) {
     const int tn = min(step, T - t0);
     const u16* xx = x + (long)t0 * ldx;
     float* oo = out + (long)t0 * ostride;      // out is [S][T][N] over the full T; split stride stays T

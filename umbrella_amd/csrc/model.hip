@@ -11,9 +11,13 @@
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
+// split count actually used: the plan's S (a function of the layer shape only, so T <= 64 results are batch
+// invariant); the wide verify (T > 64) has plenty of token-chunk parallelism and keeps the partial traffic down
+static inline int eff_s(const UmbLinear& l, int T) { return (T > 64 && l.S > 4) ? 4 : l.S; }
+
 static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int T, int dtype, hipStream_t st, int epi,
                       const UmbGemmFused* fx) {
-  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, l.S, l.R, epi, fx, dtype, st);
+  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, eff_s(l, T), l.R, epi, fx, dtype, st);
 }
 
 // embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h
@@ -40,17 +44,17 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
   CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, nullptr));
-  CK(umb_reduce_qkv_rope(ws->partial, ly.qkv.S, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
+  CK(umb_reduce_qkv_rope(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
                          m->rope_sin, ws->q, kc, vt, /*paired=*/1, dt, st));
   CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
                    nullptr, dt, st));
   CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr));
-  CK(umb_reduce_residual_norm(ws->partial, ly.o.S, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.o, T), T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
   CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
   CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr));
-  CK(umb_reduce_residual_norm(ws->partial, ly.down.S, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
+  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.down, T), T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
                               m->eps, dt, st));
   return UMB_OK;
 }
