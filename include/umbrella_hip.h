@@ -112,6 +112,17 @@ int umb_argmax_rows(int* out, const float* logits, int rows, int V, umb_stream_t
  * placement tokens_all[*n_ptr + child_start[row] + r] = idx[r], r < child_cnt[row] (static:115-123,279-281) */
 int umb_topk_rows(int* out_idx, float* out_val, const float* logits, int rows, int V, int k, int* tokens_all,
                   const int* n_ptr, const int* child_start, const int* child_cnt, umb_stream_t stream);
+/* verification sampling, one token per tree node (static_speculation_engine.py:298-310,
+ * dynamic_speculation_engine.py:266-281; helpers speculation_utils.py:340-352; replaces
+ * flashinfer.sampling.top_k_top_p_sampling_from_logits / top_p_renorm_prob + torch.multinomial):
+ * HF repetition penalty over tokens_all[0..*n_ptr] when penalty > 1.01 (applied to `logits` in place), then
+ * arg-max if temperature < 0.05, else top-k (ties at the k-th value kept) -> softmax(x / temperature) -> top-p
+ * renormalisation -> one draw keyed by (*seed [u64, device], *n_ptr, row).  Optional dbg_k > 0: the first dbg_k
+ * entries of the sorted filtered distribution (token or -1, renormalised probability) per row.
+ * Needs topk <= 1024, topp > 0, V <= 1048576 when the penalty is on. */
+int umb_sample_rows(int* sampled, float* logits, int rows, int V, const int* tokens_all, const int* n_ptr,
+                    float penalty, float temperature, int topk, float topp, const void* seed, int dbg_k,
+                    int* dbg_idx, float* dbg_p, umb_stream_t stream);
 /* SpecExec beam expansion of one level (dynamic_speculation_engine.py:236-248) */
 int umb_beam_expand(const int* top_idx, const float* top_val, int w, int B, int W, int lvl_off, float* tree_score,
                     int* parents, int* tokens_all, const int* n_ptr, void* mask_bits, int mask_words,

@@ -195,6 +195,34 @@ def test_stochastic_sampling_support(dev):
         assert rank < 8 + 2, (i, tok, rank)          # inside top-k (+2 slack for 16-bit near-ties at the boundary)
 
 
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+def test_stochastic_graph_equals_eager_and_reseed(dev, kind):
+    """The stochastic iteration (penalty + top-k/top-p sampling kernel) replays as one hipGraph and gives the same
+    tokens as eager launches under the same seed; a new seed (device-resident) changes the stream without
+    recapture; changing the sampling knobs drops the graph."""
+    from hip_helpers import dynamic_engine, static_engine
+    dtype = torch.bfloat16
+    kw = dict(temperature=0.8, topp=0.95, topk=16, repetition_penalty=1.1, seed=5)
+    outs = []
+    for graph in (True, False):
+        if kind == "static":
+            eng, _ = static_engine(G, dev, dtype, self_draft=True, hip_graph=graph, **kw)
+        else:
+            eng, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=4, num_beams=6, depth=3, hip_graph=graph, **kw)
+        outs.append(eng.generate(input_ids=PROMPT, max_new_tokens=32)["generated_tokens"])
+        if graph:
+            assert eng._graph is not None
+            again = eng.generate(input_ids=PROMPT, max_new_tokens=32)["generated_tokens"]
+            assert again == outs[0]                              # same seed, same history -> same draws
+            g0 = eng._graph
+            eng.manual_seed(6)
+            other = eng.generate(input_ids=PROMPT, max_new_tokens=32)["generated_tokens"]
+            assert eng._graph is g0 and other != outs[0]
+            eng.update_generation_args(temperature=0.3)
+            assert eng._graph is None
+    assert outs[0] == outs[1]
+
+
 def test_reference_face_and_awq_linear(dev):
     """AutoEngine / AutoModelLM / AwqLinear keep the reference's contracts."""
     from umbrella_amd.models import AutoModelLM

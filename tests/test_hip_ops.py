@@ -237,6 +237,84 @@ def test_topk_places_sequoia_children(dev):
     assert tokens.cpu()[17:].abs().sum() == 0 and tokens.cpu()[:14].abs().sum() == 0
 
 
+def _oracle_filtered(logits, hist, penalty, temperature, topk, topp):
+    """The reference's filtered target distribution (static:298-310 / dynamic:266-281) through the oracle ops."""
+    lg = logits.clone()
+    if penalty > 1.01:
+        lg = O.repetition_penalty(hist[None].expand(lg.shape[0], -1), lg, penalty)
+    pen = lg.clone()
+    lg = O.keep_topk(lg, topk)
+    return pen, O.top_p_renorm(torch.softmax(lg / temperature, dim=-1), topp)
+
+
+@pytest.mark.parametrize("V,topk,penalty", [(512, 8, 1.0), (128256, 32, 1.05), (5001, 32, 1.3), (128256, 64, 1.0)])
+def test_sample_rows_distribution(dev, V, topk, penalty):
+    """umb_sample_rows: the filtered, renormalised distribution equals the oracle's (penalty with duplicate
+    history tokens, top-k, temperature, top-p); draws land in its support and follow it (chi-square)."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(V + topk)
+    rows, n = 6, 200
+    logits = torch.randn(rows, V, generator=g) * 3.0
+    hist = torch.randint(0, V, (n + 1,), generator=g)
+    hist[5:40] = hist[0]                                   # duplicates: penalised once
+    hist[50:60] = logits[0].topk(10)[1]                    # make the penalty matter for row 0's head
+    temperature, topp = 0.6, 0.9
+    pen, p_ref = _oracle_filtered(logits, hist, penalty, temperature, topk, topp)
+    tokens = torch.zeros(n + 64, dtype=torch.int32); tokens[:n + 1] = hist.int()
+    tokens, nd = tokens.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+    seed = torch.tensor([1234], dtype=torch.int64, device=dev)
+    sampled = torch.zeros(rows, dtype=torch.int32, device=dev)
+    dk = 128
+    di = torch.zeros(rows, dk, dtype=torch.int32, device=dev); dp = torch.zeros(rows, dk, device=dev)
+    d = logits.to(dev).clone()
+    _lib.call("umb_sample_rows", sampled, d, rows, V, tokens, nd, penalty, temperature, topk, topp, seed, dk, di, dp)
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), pen), "in-place repetition penalty differs from the oracle's gather/scatter"
+    di, dp = di.cpu(), dp.cpu()
+    for r in range(rows):
+        got = torch.zeros(V)
+        keep = di[r] >= 0
+        got[di[r][keep].long()] = dp[r][keep]
+        assert torch.allclose(got, p_ref[r], atol=2e-6, rtol=1e-4), (r, (got - p_ref[r]).abs().max())
+        assert p_ref[r, sampled[r].item()] > 0
+    # chi-square on 4000 draws of row 0 (fresh n => fresh draw each launch)
+    draws = torch.zeros(4000, dtype=torch.int32, device=dev)
+    for i in range(4000):
+        nd.fill_(n)            # history unchanged ...
+        seed.fill_(i)          # ... new stream
+        _lib.call("umb_sample_rows", draws[i:i + 1], d[:1].clone() if penalty <= 1.01 else logits[:1].to(dev).clone(),
+                  1, V, tokens, nd, penalty, temperature, topk, topp, seed, 0, None, None)
+    cnt = torch.bincount(draws.cpu().long(), minlength=V).float()
+    exp = p_ref[0] * 4000
+    assert cnt[exp == 0].sum() == 0
+    big = exp >= 5
+    chi = (((cnt - exp) ** 2)[big] / exp[big]).sum().item()
+    dof = int(big.sum()) - 1
+    assert chi < dof + 5 * (2 * max(dof, 1)) ** 0.5 + 10, (chi, dof)
+
+
+def test_sample_rows_greedy_with_penalty_and_seed(dev):
+    """temperature < 0.05 with a penalty: arg-max of the penalised row; same (seed, n) -> same draw."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    V, rows, n = 4096, 5, 30
+    logits = torch.randn(rows, V, generator=g)
+    hist = torch.cat([logits.argmax(-1), torch.randint(0, V, (n + 1 - rows,), generator=g)])
+    tokens = torch.zeros(n + 8, dtype=torch.int32); tokens[:n + 1] = hist.int()
+    tokens, nd = tokens.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+    seed = torch.tensor([7], dtype=torch.int64, device=dev)
+    out = torch.zeros(rows, dtype=torch.int32, device=dev)
+    _lib.call("umb_sample_rows", out, logits.to(dev).clone(), rows, V, tokens, nd, 1.5, 0.0, 32, 0.9, seed, 0, None, None)
+    exp = O.repetition_penalty(hist[None].expand(rows, -1), logits, 1.5).argmax(-1)
+    assert out.cpu().tolist() == exp.tolist()
+    a = torch.zeros(rows, dtype=torch.int32, device=dev); b = torch.zeros_like(a)
+    for dst in (a, b):
+        _lib.call("umb_sample_rows", dst, logits.to(dev).clone(), rows, V, tokens, nd, 1.0, 0.8, 32, 0.95, seed, 0, None, None)
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        _lib.call("umb_sample_rows", a, logits.to(dev).clone(), rows, V, tokens, nd, 1.0, 0.8, 2000, 0.95, seed, 0, None, None)
+
+
 def test_accept_scan_matches_oracle(dev):
     from oracle import sequoia
     from umbrella_amd import _lib

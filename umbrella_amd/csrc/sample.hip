@@ -92,21 +92,12 @@ __device__ __forceinline__ void bitonic_desc_1024(unsigned long long* s) {
   __syncthreads();
 }
 
-// ---- row top-k (k <= 64): threshold = k-th largest of the 1024 per-thread maxima, then
-// collect every element >= threshold (>= k of them, few in practice) and sort those.
-// Optionally places the first child_cnt[row] winners as Sequoia children:
-//   tokens_all[n + child_start[row] + r] = idx[r]
-__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict__ logits, int V, int k,
-                                                         int* __restrict__ out_idx, float* __restrict__ out_val,
-                                                         int* __restrict__ tokens_all, const int* __restrict__ n_ptr,
-                                                         const int* __restrict__ child_start,
-                                                         const int* __restrict__ child_cnt) {
-  __shared__ unsigned long long s[1024];
-  __shared__ unsigned long long cand[1024];
-  __shared__ int ncand;
-  const float* row = logits + (long)blockIdx.x * V;
+// top-k selection body shared by topk_rows_kernel and sample_rows_kernel: on return cand[0..min(nc,1024)) holds the
+// keys >= threshold sorted descending (the first k are the row's top-k); in the tie-flood fallback exactly k entries.
+__device__ __forceinline__ int topk_select(const float* __restrict__ row, int V, int k, unsigned long long* s,
+                                           unsigned long long* cand, int* ncand_p) {
   s[threadIdx.x] = scan_row_max(row, V);
-  if (threadIdx.x == 0) ncand = 0;
+  if (threadIdx.x == 0) *ncand_p = 0;
   bitonic_desc_1024(s);
   const unsigned long long thr = s[min(k, 1024) - 1];
   __syncthreads();
@@ -125,17 +116,17 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e)
           if (q[u][e] >= thr_v && i + u * 1024 < (V >> 2)) {
             const unsigned long long key = mk_key(q[u][e], (i + u * 1024) * 4 + e);
-            if (key >= thr) { const int slot = atomicAdd(&ncand, 1); if (slot < 1024) cand[slot] = key; }
+            if (key >= thr) { const int slot = atomicAdd(ncand_p, 1); if (slot < 1024) cand[slot] = key; }
           }
     }
   } else {
     for (int i = threadIdx.x; i < V; i += 1024) {
       const unsigned long long key = mk_key(row[i], i);
-      if (key >= thr) { const int slot = atomicAdd(&ncand, 1); if (slot < 1024) cand[slot] = key; }
+      if (key >= thr) { const int slot = atomicAdd(ncand_p, 1); if (slot < 1024) cand[slot] = key; }
     }
   }
   __syncthreads();
-  const int nc = ncand;
+  const int nc = *ncand_p;
   if (nc <= 1024) {
     bitonic_desc_1024(cand);
   } else {
@@ -160,6 +151,22 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
     }
     __syncthreads();
   }
+  return nc;
+}
+
+// ---- row top-k (k <= 64): threshold = k-th largest of the 1024 per-thread maxima, then
+// collect every element >= threshold (>= k of them, few in practice) and sort those.
+// Optionally places the first child_cnt[row] winners as Sequoia children:
+//   tokens_all[n + child_start[row] + r] = idx[r]
+__global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict__ logits, int V, int k,
+                                                         int* __restrict__ out_idx, float* __restrict__ out_val,
+                                                         int* __restrict__ tokens_all, const int* __restrict__ n_ptr,
+                                                         const int* __restrict__ child_start,
+                                                         const int* __restrict__ child_cnt) {
+  __shared__ unsigned long long s[1024];
+  __shared__ unsigned long long cand[1024];
+  __shared__ int ncand;
+  topk_select(logits + (long)blockIdx.x * V, V, k, s, cand, &ncand);
   if (threadIdx.x < k) {
     const unsigned long long key = cand[threadIdx.x];
     const int idx = key_idx(key);
@@ -167,6 +174,90 @@ __global__ __launch_bounds__(1024) void topk_rows_kernel(const float* __restrict
     if (out_val) out_val[(long)blockIdx.x * k + threadIdx.x] = key_val(key);
     if (tokens_all && threadIdx.x < child_cnt[blockIdx.x])
       tokens_all[*n_ptr + child_start[blockIdx.x] + threadIdx.x] = idx;
+  }
+}
+
+// ---- verification sampling for one tree node per block (static:298-310, dynamic:266-281):
+//   HF repetition penalty over the history tokens[0..n] (speculation_utils.py:340-345; duplicates penalised once,
+//   as gather/scatter does) -> top-k filter (ties at the k-th value kept, apply_topk :347-352) -> softmax(x/T) ->
+//   top-p renormalisation (smallest prefix of the sorted distribution reaching topp) -> one inverse-CDF draw.
+// greedy (temperature < 0.05): arg-max of the penalised row.  The draw uses a counter-based generator keyed by
+// (*seed, num_nodes, row): reproducible under a seed, different every iteration, graph-replay safe.
+// The penalty is applied to the logits row in place (the row is scratch for this iteration).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(1024) void sample_rows_kernel(float* __restrict__ logits, int V, int k,
+                                                           const int* __restrict__ tokens_all,
+                                                           const int* __restrict__ n_ptr, float penalty,
+                                                           float temperature, float topp,
+                                                           const unsigned long long* __restrict__ seed,
+                                                           int* __restrict__ sampled, int dbg_k,
+                                                           int* __restrict__ dbg_idx, float* __restrict__ dbg_p) {
+  __shared__ unsigned long long s[1024];
+  __shared__ unsigned long long cand[1024];
+  __shared__ int ncand;
+  extern __shared__ unsigned seen[];                          // V bits
+  const int tid = threadIdx.x;
+  float* row = logits + (long)blockIdx.x * V;
+  const int n = *n_ptr;
+  if (penalty > 1.01f) {
+    for (int i = tid; i < (V + 31) / 32; i += 1024) seen[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i <= n; i += 1024) {
+      const int v = tokens_all[i];
+      if (v < 0 || v >= V) continue;
+      const unsigned bit = 1u << (v & 31);
+      if (!(atomicOr(&seen[v >> 5], bit) & bit)) {
+        const float x = row[v];
+        row[v] = x < 0.f ? x * penalty : x / penalty;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const int nc = topk_select(row, V, k, s, cand, &ncand);
+  const int have = nc <= 1024 ? nc : k;
+  if (temperature < 0.05f) {
+    if (tid == 0) sampled[blockIdx.x] = key_idx(cand[0]);
+    if (tid < dbg_k) { dbg_idx[(long)blockIdx.x * dbg_k + tid] = tid == 0 ? key_idx(cand[0]) : -1; dbg_p[(long)blockIdx.x * dbg_k + tid] = tid == 0 ? 1.f : 0.f; }
+    return;
+  }
+  const float v0 = key_val(cand[0]), vk = key_val(cand[k - 1]);
+  const bool active = tid < have && key_val(cand[tid]) >= vk;
+  const float e = active ? expf((key_val(cand[tid]) - v0) / temperature) : 0.f;
+  float* cum = reinterpret_cast<float*>(s);                   // inclusive scan of e (sorted descending)
+  __syncthreads();
+  cum[tid] = e;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const float add = tid >= o ? cum[tid - o] : 0.f;
+    __syncthreads();
+    cum[tid] += add;
+    __syncthreads();
+  }
+  const float total = cum[1023];
+  const bool keep = active && (cum[tid] - e) < topp * total;  // mass before this element < topp
+  __shared__ int kc_s, sel_s;
+  if (tid == 0) { kc_s = 0; sel_s = 0; }
+  __syncthreads();
+  if (keep) atomicAdd(&kc_s, 1);
+  __syncthreads();
+  const int kc = kc_s;                                        // kept entries are a prefix of the sorted list
+  const float kept_mass = cum[kc - 1];
+  const unsigned long long r = mix64(mix64(*seed ^ ((unsigned long long)(unsigned)n << 32)) + blockIdx.x);
+  const float u = (float)(r >> 40) * (1.0f / 16777216.0f);    // [0,1)
+  const float target = u * kept_mass;
+  if (keep && cum[tid] <= target) atomicAdd(&sel_s, 1);
+  __syncthreads();
+  if (tid == 0) sampled[blockIdx.x] = key_idx(cand[min(sel_s, kc - 1)]);
+  if (tid < dbg_k) {
+    dbg_idx[(long)blockIdx.x * dbg_k + tid] = keep ? key_idx(cand[tid]) : -1;
+    dbg_p[(long)blockIdx.x * dbg_k + tid] = keep ? e / kept_mass : 0.f;
   }
 }
 
@@ -344,6 +435,22 @@ extern "C" int umb_topk_rows(int* out_idx, float* out_val, const float* logits, 
   if (rows < 1 || k < 1 || k > 64 || V < k) return UMB_EINVAL;
   hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(1024), 0, st, logits, V, k, out_idx, out_val, tokens_all, n_ptr,
                      child_start, child_cnt);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_sample_rows(int* sampled, float* logits, int rows, int V, const int* tokens_all, const int* n_ptr,
+                               float penalty, float temperature, int topk, float topp, const void* seed, int dbg_k,
+                               int* dbg_idx, float* dbg_p, hipStream_t st) {
+  if (rows < 1 || topk < 1 || topk > 1024 || V < topk || !(topp > 0.f) || !seed || dbg_k < 0 || dbg_k > 1024) return UMB_EINVAL;
+  const size_t sm = penalty > 1.01f ? (size_t)((V + 31) / 32) * 4 : 0;
+  if (sm > 128 * 1024) return UMB_EINVAL;                    // vocabulary bitmap must fit LDS beside the sort buffers
+  if (sm > 40 * 1024) {
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void*)sample_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); raised = true; }
+  }
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(1024), sm, st, logits, V, topk, tokens_all, n_ptr, penalty,
+                     temperature, topp, (const unsigned long long*)seed, sampled, dbg_k, dbg_idx, dbg_p);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

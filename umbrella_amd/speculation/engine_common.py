@@ -91,7 +91,7 @@ class HipEngine(BaseEngine):
         self.eos_dev = torch.tensor(self.eos_tokens or [-1], dtype=torch.int32, device=dev)
         self.num_nodes = 0
         self._graph = None
-        self._rng = torch.Generator(device=dev).manual_seed(self.seed)
+        self.rng_state = torch.tensor([self.seed], dtype=torch.int64, device=dev)    # device-resident: reseed without recapture
         self.draft_model.reserve(max(self.draft_model.CHUNK, self.draft_rows))
         self.target_model.reserve(max(self.target_model.CHUNK, tree_size))
 
@@ -146,28 +146,20 @@ class HipEngine(BaseEngine):
     def _greedy(self):
         return self.temperature < 0.05 and not (self.repetition_penalty > 1.01)
 
-    def _sample_eager(self):
-        """Non-greedy / penalised path: torch ops on the fp32 logits, then the same accept scan."""
-        T, n = self.tree_size, self.num_nodes
-        logits = self.target_model.logits_buffer[:T]
-        if self.repetition_penalty > 1.01:                            # speculation_utils.py:340-345
-            hist = self.tokens[:n + 1].long()[None].expand(T, -1)
-            g = torch.gather(logits, 1, hist)
-            g = torch.where(g < 0, g * self.repetition_penalty, g / self.repetition_penalty)
-            logits = logits.scatter(1, hist, g)
-        if self.temperature < 0.05:
-            self.sampled.copy_(logits.argmax(dim=-1).int())
+    def _sample(self, dbg=None):
+        """One token per tree node from the target logits (static:298-310, dynamic:266-281): arg-max when greedy
+        and unpenalised, otherwise umb_sample_rows (penalty -> top-k -> softmax(x/T) -> top-p -> draw), all on
+        the device so the stochastic iteration is graph-replayable too."""
+        T = self.tree_size
+        logits = self.target_model.logits_buffer
+        if self._greedy():
+            _lib.call("umb_argmax_rows", self.sampled, logits, T, self.vocab_size)
             return
-        k = min(self.topk, logits.size(-1))                           # apply_topk, speculation_utils.py:347-352
-        kth = torch.topk(logits, k)[0][..., -1, None]
-        logits = logits.masked_fill(logits < kth, torch.finfo(logits.dtype).min)
-        p = torch.softmax(logits / self.temperature, dim=-1)
-        sp, si = torch.sort(p, dim=-1, descending=True)               # top-p renormalisation
-        drop = (torch.cumsum(sp, dim=-1) - sp) >= self.topp
-        sp = sp.masked_fill(drop, 0.0)
-        p = torch.zeros_like(p).scatter(-1, si, sp)
-        p = p / p.sum(dim=-1, keepdim=True)
-        self.sampled.copy_(torch.multinomial(p, 1, generator=self._rng).squeeze(-1).int())
+        k = min(int(self.topk), self.vocab_size)
+        dk, di, dp = (0, None, None) if dbg is None else (dbg[0].shape[1], dbg[0], dbg[1])
+        _lib.call("umb_sample_rows", self.sampled, logits, T, self.vocab_size, self.tokens, self.n_dev,
+                  float(self.repetition_penalty), float(self.temperature), k, float(self.topp), self.rng_state,
+                  dk, di, dp)
 
     def _commit(self):
         _lib.call("umb_accept_scan", self.sampled, self.parents, self.tokens, self.n_dev, self.tree_size,
@@ -179,14 +171,12 @@ class HipEngine(BaseEngine):
     def _iteration_launch(self):
         self.build_tree()
         self._verify_forward()
-        if self._greedy():
-            _lib.call("umb_argmax_rows", self.sampled, self.target_model.logits_buffer, self.tree_size, self.vocab_size)
-        else:
-            self._sample_eager()
+        self._sample()
         self._commit()
 
     def _capture(self):
-        """Capture one full greedy iteration into a hipGraph (replayed by step())."""
+        """Capture one full iteration into a hipGraph (replayed by step()).  Sampling knobs are launch arguments,
+        hence frozen into the graph: update_generation_args drops the graph when they change."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         n_save = self.n_dev.clone()
@@ -208,7 +198,7 @@ class HipEngine(BaseEngine):
         """build_tree + verify as one launch; returns continue_generation."""
         if getattr(self, "enable_override", False):
             self._fill_override()
-        if self.use_graph and self._greedy():
+        if self.use_graph:
             if self._graph is None:
                 self._capture()
             self._graph.replay()
@@ -228,10 +218,7 @@ class HipEngine(BaseEngine):
     @torch.inference_mode()
     def verify(self):
         self._verify_forward()
-        if self._greedy():
-            _lib.call("umb_argmax_rows", self.sampled, self.target_model.logits_buffer, self.tree_size, self.vocab_size)
-        else:
-            self._sample_eager()
+        self._sample()
         self._commit()
         return self._finish_iteration()
 
@@ -240,10 +227,17 @@ class HipEngine(BaseEngine):
         return self.num_nodes <= (self.max_length - self.safe_buffer)
 
     def update_generation_args(self, **generation_args):
+        before = (self.temperature, self.topp, self.repetition_penalty, self.topk)
         self.temperature = generation_args.pop("temperature", self.temperature)
         self.topp = generation_args.pop("topp", self.topp)
         self.repetition_penalty = generation_args.pop("repetition_penalty", self.repetition_penalty)
         self.topk = generation_args.pop("topk", self.topk)
+        if before != (self.temperature, self.topp, self.repetition_penalty, self.topk):
+            self._graph = None
+
+    def manual_seed(self, seed: int):
+        self.seed = seed
+        self.rng_state.fill_(seed)
 
     @torch.inference_mode()
     def reset(self):
