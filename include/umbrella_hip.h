@@ -23,6 +23,12 @@
 extern "C" {
 #endif
 
+/* Every V^T cache (vt_cache arguments below) has rows of Lmax + UMB_VT_PAD elements: with a power-of-two row
+ * stride the 16 d-rows one MFMA fragment load touches fall on one memory channel. */
+#ifndef UMB_VT_PAD
+#define UMB_VT_PAD 32
+#endif
+
 typedef struct ihipStream_t* umb_stream_t;   /* == hipStream_t */
 
 /* ------------------------------------------------------------------ weights (load time) */
@@ -78,7 +84,7 @@ int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const voi
 int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
  * + KV_Cache.update_kv_cache (umbrella/attn/cache.py:53-65) at slots slot[t].
- * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax] (layer base pointers).
+ * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax + UMB_VT_PAD] (layer base pointers).
  * paired != 0: the q/k rows of the linear were packed as RoPE partner pairs (repack mode 2). */
 int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
                         const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
@@ -164,7 +170,7 @@ typedef struct UmbModel {
   const void* rope_cos;             /* [Lmax][D] model dtype (umbrella/models/llama.py:48-60) */
   const void* rope_sin;
   void* k_cache;                    /* [L][Hkv][Lmax][D] */
-  void* vt_cache;                   /* [L][Hkv][D][Lmax] */
+  void* vt_cache;                   /* [L][Hkv][D][Lmax + UMB_VT_PAD] */
   const UmbLayer* layers;           /* host array, L entries */
 } UmbModel;
 

@@ -8,6 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ops as O                                     # noqa: E402
+from umbrella_amd.attn.cache import VT_PAD                      # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -118,7 +119,7 @@ def test_qkv_rope_kv_append(dev, dtype):
     cos, sin = O.rope_cache(inv, 1.0, Lmax, dtype)
     q = torch.zeros(T, Hq, D, dtype=dtype, device=dev)
     kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev)
-    vt = torch.zeros(Hkv, D, Lmax, dtype=dtype, device=dev)
+    vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype, device=dev)
     _lib.call("umb_reduce_qkv_rope", part.to(dev), 2, T, Hq, Hkv, D, Lmax, pos.to(dev), slot.to(dev), cos.to(dev),
               sin.to(dev), q, kc, vt, 0, _lib.dtype_code(dtype))
     full = part.sum(0).to(dtype)
@@ -164,7 +165,7 @@ def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix):
     mask = torch.cat([torch.ones(T, prefix, dtype=torch.bool), tm], dim=1)
     ref = O.masked_attention(q.float(), k.float(), v.float(), mask)
     kc = torch.zeros(Hkv, Lmax, D, dtype=dtype)
-    vt = torch.zeros(Hkv, D, Lmax, dtype=dtype)
+    vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype)
     kc[:, :S] = k.permute(1, 0, 2)
     vt[:, :, :S] = v.permute(1, 2, 0)
     # stale garbage after the valid region must be ignored
@@ -475,7 +476,7 @@ def test_gemm_fused_qkv_epilogue(dev, dtype, T, awq):
     counters = torch.zeros(64, dtype=torch.int32, device=dev)
     part = torch.empty(lin.S * T * N + 64, dtype=torch.float32, device=dev)
     qo = torch.zeros(T, Hq, D, dtype=dtype, device=dev)
-    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev); vt = torch.zeros(Hkv, D, Lmax, dtype=dtype, device=dev)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev); vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype, device=dev)
     keep = [x.to(dev), ssq.to(dev), pos.to(dev), slot.to(dev), cos.to(dev), sin.to(dev)]
     fx = _lib.UmbGemmFused()
     fx.ssq_in, fx.ssq_groups, fx.ssq_dim, fx.eps = keep[1].data_ptr(), stride, float(K), 1e-5

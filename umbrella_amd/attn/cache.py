@@ -4,7 +4,8 @@ Replaces umbrella/attn/cache.py (KV_Cache :5-96, StaticKV_Cache :98-192) with on
 layout chosen for the HIP attention kernel's 16-byte MFMA fragment loads:
 
     K  [L][Hkv][Lmax][D]        (row = one key, contiguous D)
-    V^T[L][Hkv][D][Lmax]        (transposed: 8 consecutive keys of one d are 16 B)
+    V^T[L][Hkv][D][Lmax + VT_PAD]  (transposed: 8 consecutive keys of one d are 16 B; rows padded so the
+                                 16 d-rows of a fragment load spread over memory channels)
 
 Slots are addressed explicitly (StaticKV semantics); appending is "slot ==
 kv_offset".  ``gather_kv_incremental`` keeps the reference signature; the engines
@@ -18,13 +19,15 @@ import torch
 
 from .. import _lib
 
+VT_PAD = 32          # == UMB_VT_PAD (include/umbrella_hip.h)
+
 
 class TreeKVCache:
     def __init__(self, num_layers, num_kv_heads, head_dim, max_length, device, dtype):
         self.num_layers, self.num_key_value_heads, self.head_dim = num_layers, num_kv_heads, head_dim
         self.max_length, self.device, self.dtype = max_length, device, dtype
         self.k = torch.zeros(num_layers, num_kv_heads, max_length, head_dim, device=device, dtype=dtype)
-        self.vt = torch.zeros(num_layers, num_kv_heads, head_dim, max_length, device=device, dtype=dtype)
+        self.vt = torch.zeros(num_layers, num_kv_heads, head_dim, max_length + VT_PAD, device=device, dtype=dtype)
         self.kv_offset = 0
 
     # reference API (cache.py:41-49): indices are absolute slots, moved to [offset, offset+len)

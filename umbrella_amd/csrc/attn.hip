@@ -9,12 +9,12 @@
 // set (mask_bits == null: causal, b <= t).
 //
 // Layout (chosen for 16-byte MFMA fragment loads, wave64):
-//   q   [T][Hq][D]            K cache [Hkv][Lmax][D]        V cache TRANSPOSED [Hkv][D][Lmax]
+//   q   [T][Hq][D]            K cache [Hkv][Lmax][D]        V cache TRANSPOSED [Hkv][D][Lmax + UMB_VT_PAD]
 // Per kv head the T*g query rows (g = Hq/Hkv) form 16-row tiles.  The kernel
 // computes S^T = K Q^T so each lane owns ONE query column: softmax statistics
 // are lane-local (+2 cross-lane xor steps), and the exp'd scores are already in
 // B-operand layout for O^T = V^T P^T -- no LDS, no transposes.
-//   grid = (key splits, Hkv, query-tile groups); partial (m, l, O) per split are
+//   grid = (Hkv, query-tile groups, key splits); partial (m, l, O) per split are
 //   merged by attn_combine_kernel.
 #include "common.h"
 
@@ -33,7 +33,10 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, gq = lane >> 4;
-  const int sp = blockIdx.x, h = blockIdx.y;
+  // grid = (Hkv, query-tile groups, key splits): workgroups are dealt round-robin to the 8 XCDs by linear id, so
+  // kv head h stays on XCD h % 8 (its K/V is fetched into one L2) and the splits past kv_end -- which exit at
+  // once -- are the slowest dimension.  (With the splits fastest, a 2-split verify ran on 2 of the 8 XCDs.)
+  const int sp = blockIdx.z, h = blockIdx.x, zq = blockIdx.y;
   const int g = Hq / Hkv;
   const int nrows = T * g;
   const int prefix = *prefix_p;
@@ -42,11 +45,12 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
   if (k_lo >= kv_end) return;
   const int k_hi = min(kv_end, k_lo + chunk);
   const u16* kbase = kc + (long)h * Lmax * D;
-  const u16* vbase = vt + (long)h * D * Lmax;
+  const long LV = VT_LD(Lmax);
+  const u16* vbase = vt + (long)h * D * LV;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   for (int qi = 0; qi < qtiles_per_wave; ++qi) {
-    const int qt = (blockIdx.z * 4 + wv) * qtiles_per_wave + qi;
+    const int qt = (zq * 4 + wv) * qtiles_per_wave + qi;
     if (qt * 16 >= nrows) break;
     const int row = qt * 16 + j;                 // this lane's query row (column of S^T)
     const bool row_ok = row < nrows;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
       u32x4 av[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * Lmax + k0 + gq * 8);
+        av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * LV + k0 + gq * 8);
       f32x4 st[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned* cnt = counters + (long)h * gridDim.z + blockIdx.z;
+    unsigned* cnt = counters + (long)h * gridDim.y + zq;
     const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (unsigned)(nsp - 1);
     if (last) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
   if (!s_last) return;
   const long rows_all = (long)T * Hq;
   for (int qi = 0; qi < qtiles_per_wave; ++qi) {
-    const int qt = (blockIdx.z * 4 + wv) * qtiles_per_wave + qi;
+    const int qt = (zq * 4 + wv) * qtiles_per_wave + qi;
     if (qt * 16 >= nrows) break;
     const int row = qt * 16 + j;
     if (row >= nrows) continue;
@@ -279,7 +283,7 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
   int qpw = 1;
   while ((nqt + 4 * qpw - 1) / (4 * qpw) > 64 && qpw < 8) qpw *= 2;
   const int gz = (nqt + 4 * qpw - 1) / (4 * qpw);
-  const dim3 grid(max_splits, Hkv, gz), block(256);
+  const dim3 grid(Hkv, gz, max_splits), block(256);
   const int rows = T * Hq;
 #define ATT_(DD)                                                                                                  \
   hipLaunchKernelGGL((tree_attn_kernel<P, DD>), grid, block, 0, st, (const u16*)q, (const u16*)k_cache,            \

@@ -1,5 +1,12 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of umbrella_amd.
 #pragma once
+// V^T cache rows are padded: a power-of-two row stride puts the 16 d-rows one MFMA fragment load touches on the
+// same memory channel (measured 9-14 % on the attention kernel: T=257 55 -> 50 us, T=769 267 -> 233 us).  Same value
+// as umbrella_hip.h.
+#ifndef UMB_VT_PAD
+#define UMB_VT_PAD 32
+#endif
+#define VT_LD(Lmax) ((Lmax) + UMB_VT_PAD)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void reduce_silu_mul_kernel(const float* __res
 
 // ---- QKV reduce + RoPE + KV append.  One block per (token, head) with D/2 active pairs.
 // partial row layout: [q (Hq*D) | k (Hkv*D) | v (Hkv*D)]
-// K cache: [Hkv][Lmax][D] ; V cache transposed: [Hkv][D][Lmax]   (layer base pointers)
+// K cache: [Hkv][Lmax][D] ; V cache transposed: [Hkv][D][Lmax + UMB_VT_PAD]   (layer base pointers)
 template <typename P>
 __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __restrict__ part, int S, int T, int Hq,
                                                              int Hkv, int D, int Lmax, const int* __restrict__ pos,
@@ -154,9 +154,10 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
         ko[d] = P::from_f(o0); ko[d + half] = P::from_f(o1);
       }
     } else {
-      u16* vo = vt + (long)(head - Hq - Hkv) * D * Lmax + sl;
-      vo[(long)d * Lmax] = P::from_f(a);
-      vo[(long)(d + half) * Lmax] = P::from_f(b);
+      const long LV = VT_LD(Lmax);
+      u16* vo = vt + (long)(head - Hq - Hkv) * D * LV + sl;
+      vo[(long)d * LV] = P::from_f(a);
+      vo[(long)(d + half) * LV] = P::from_f(b);
     }
   }
 }

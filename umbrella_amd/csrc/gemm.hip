@@ -535,9 +535,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
         *reinterpret_cast<unsigned*>(dst + m) = pack2<P>(lo0, lo1);
         *reinterpret_cast<unsigned*>(dst + m + half) = pack2<P>(hi0, hi1);
       } else {
-        u16* dst = fx.vt + ((long)(head - fx.Hq - fx.Hkv) * D + dp) * fx.Lmax + sl;
-        dst[0] = P::from_f(a0); dst[fx.Lmax] = P::from_f(b0);
-        dst[2L * fx.Lmax] = P::from_f(a1); dst[3L * fx.Lmax] = P::from_f(b1);
+        const long LV = VT_LD(fx.Lmax);
+        u16* dst = fx.vt + ((long)(head - fx.Hq - fx.Hkv) * D + dp) * LV + sl;
+        dst[0] = P::from_f(a0); dst[LV] = P::from_f(b0);
+        dst[2L * LV] = P::from_f(a1); dst[3L * LV] = P::from_f(b1);
       }
     }
   }

@@ -42,7 +42,7 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   const int T = s->T, dt = m->dtype;
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
-  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
   CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_qkv_rope(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
                          m->rope_sin, ws->q, kc, vt, /*paired=*/1, dt, st));
@@ -66,7 +66,7 @@ static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   const int T = s->T, dt = m->dtype;
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
-  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
   UmbGemmFused fx = {};
   // 1. qkv GEMM -> (last split block) 1/rms, RoPE at tree positions, q out, K/V appended at their slots
   fx.ssq_in = ws->ssq; fx.ssq_groups = ws->ssq_stride; fx.ssq_dim = (float)m->H; fx.eps = m->eps;

@@ -384,20 +384,21 @@ __global__ __launch_bounds__(256) void kv_compact_kernel(u16* __restrict__ kc, u
   const int n_old = res[3] - res[0];
   const int h = blockIdx.x, layer = blockIdx.y;
   u16* kb = kc + ((long)layer * Hkv + h) * Lmax * D;
-  u16* vb = vt + ((long)layer * Hkv + h) * D * Lmax;
+  const long LV = VT_LD(Lmax);
+  u16* vb = vt + ((long)layer * Hkv + h) * D * LV;
   const int total = keep * D;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e / D, d = e % D;
     const int src = n_old + path[i];
     sk[e] = kb[(long)src * D + d];
-    sv[e] = vb[(long)d * Lmax + src];
+    sv[e] = vb[(long)d * LV + src];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e / D, d = e % D;
     if (path[i] == i) continue;
     kb[(long)(n_old + i) * D + d] = sk[e];
-    vb[(long)d * Lmax + n_old + i] = sv[e];
+    vb[(long)d * LV + n_old + i] = sv[e];
   }
 }
 
