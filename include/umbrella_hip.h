@@ -104,8 +104,10 @@ int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, con
  * StaticKV_Cache.compute_attention (cache.py:169-192).  Keys [0,*prefix_len) are visible to every
  * row; key *prefix_len + b is visible to row t iff bit b of mask_bits[t*mask_words ...] (NULL: b <= t).
  * po: [max_splits][T][Hq][D] fp32, pml: [max_splits][T][Hq][2] fp32 scratch; chunk*max_splits >= Lmax.
- * counters: NULL -> a second kernel merges the key splits; else >= Hkv*64 zeroed words (self-resetting) and the
- * last-arriving split block merges in-kernel. */
+ * One launch: 8 waves per (kv head, 16-row query tile) split the keys and merge in LDS; contexts beyond 2048 keys
+ * use further 2048-key span blocks merged by the last arriver, which needs `counters` (>= Hkv * ceil(T*(Hq/Hkv)/16)
+ * zeroed words, self-resetting).  counters == NULL: one launch only if Lmax <= 2048, else key splits of `chunk`
+ * keys + a combine kernel. */
 int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
                   const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T, int Hq,
                   int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, uint32_t* counters, int dtype,
@@ -183,7 +185,7 @@ typedef struct UmbWorkspace {
   void* hw;                         /* [Tmax][H] residual stream with the next RMSNorm weight folded in */
   float* ssq;                       /* [Tmax][ssq_stride] per-64-column sums of squares of h (zero padded) */
   uint32_t* counters;               /* >= max(N)/64 zeroed words for the split-K last-arriver epilogues */
-  uint32_t* attn_counters;          /* >= Hkv*64 zeroed words */
+  uint32_t* attn_counters;          /* >= Hkv * ceil(Tmax*(Hq/Hkv)/16) zeroed words */
   int32_t Tmax, attn_chunk, attn_splits, ssq_stride;
   int32_t fused, pad_;              /* layer schedule: 0 = 9 launches (split-K reduced at kernel boundaries, fastest
                                        measured on MI355X), 1 = 5 launches (in-kernel last-arriver reduces) */

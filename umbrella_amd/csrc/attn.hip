@@ -26,8 +26,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
                                                         float* __restrict__ pml, const int* __restrict__ prefix_p,
                                                         const unsigned long long* __restrict__ mask_bits,
                                                         int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
-                                                        int Lmax, int chunk, int qtiles_per_wave, float scale,
-                                                        unsigned* __restrict__ counters, u16* __restrict__ out) {
+                                                        int Lmax, int chunk, int qtiles_per_wave, float scale) {
   constexpr int DS = D / 32;     // k-steps for Q K^T
   constexpr int DT = D / 16;     // 16-row d tiles of O^T
   const int lane = threadIdx.x & 63;
@@ -161,38 +160,201 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (row_ok) {
-      // partial layout follows the output: row index = t*Hq + hq.  Write-through (sc1) stores when the
-      // merge is fused: the last-arriving block must see them without a release fence / L2 write-back.
+      // partial layout follows the output: row index = t*Hq + hq
       const long prow = ((long)sp * T + t) * Hq + hq;
-      if (counters) {
-        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
-        const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
+      float* op = po + prow * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[dt]), rs_o,
-                                                 (int)((prow * D + dt * 16 + gq * 4) * 4), 0, 16);
-        if (gq == 0) {
-          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-          u32x2 ml = {__float_as_uint(m), __float_as_uint(l)};
-          __builtin_amdgcn_raw_buffer_store_b64(ml, rs_m, (int)(prow * 8), 0, 16);
-        }
-      } else {
-        float* op = po + prow * D;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + gq * 4) = o[dt];
-        if (gq == 0) { pml[prow * 2] = m; pml[prow * 2 + 1] = l; }
-      }
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(op + dt * 16 + gq * 4) = o[dt];
+      if (gq == 0) { pml[prow * 2] = m; pml[prow * 2 + 1] = l; }
     }
   }
-  if (!counters) return;
+}
 
-  // ---- fused combine: the last key-split block to arrive for this (head, query group) merges the partials
+// ---- single-launch variant: no combine kernel.
+// Block = 8 waves on ONE 16-row query tile of one kv head and one span of KBK keys; wave w takes the 32-key tiles
+// w, w+8, w+16 ... of the span and the eight (m, l, O^T) partials are merged through LDS.  While the context fits one
+// span (kv_end <= KBK) that is the whole job: no partial buffers, no cross-block traffic -- one dependent launch
+// (>= 4.7 us) less per layer in both models.  Longer contexts activate further spans (grid z; spans past kv_end exit
+// at once): each span block publishes its merged partial with write-through stores and the last one to arrive on the
+// (head, tile) counter combines them (same protocol as the split-K epilogues).  grid = (Hkv, query tiles, spans):
+// kv head h stays on XCD h % 8.
+template <typename P, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
+                                                         const u16* __restrict__ vt, const int* __restrict__ prefix_p,
+                                                         const unsigned long long* __restrict__ mask_bits,
+                                                         int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
+                                                         int Lmax, float scale, u16* __restrict__ out, int KBK,
+                                                         float* __restrict__ po, float* __restrict__ pml,
+                                                         unsigned* __restrict__ counters) {
+  constexpr int DS = D / 32, DT = D / 16;
+  __shared__ f32x4 so[NW][DT][64];
+  __shared__ float sm[NW][16], sl[NW][16];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, gq = lane >> 4;
+  const int h = blockIdx.x, qt = blockIdx.y;
+  const int g = Hq / Hkv;
+  const int nrows = T * g;
+  const int prefix = *prefix_p;
+  const int kv_end = prefix + n_mask_keys;
+  const int k_lo = blockIdx.z * KBK;
+  if (k_lo >= kv_end) return;                                  // whole block: span not in use yet
+  const int k_hi = min(kv_end, k_lo + KBK);
+  const u16* kbase = kc + (long)h * Lmax * D;
+  const long LV = VT_LD(Lmax);
+  const u16* vbase = vt + (long)h * D * LV;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int row = qt * 16 + j;
+  const bool row_ok = row < nrows;
+  const int t = row_ok ? row / g : 0;
+  const int hq = h * g + (row_ok ? row % g : 0);
+  u32x4 bq[DS];
+#pragma unroll
+  for (int ds = 0; ds < DS; ++ds)
+    bq[ds] = row_ok ? *reinterpret_cast<const u32x4*>(q + ((long)t * Hq + hq) * D + ds * 32 + gq * 8) : zero4;
+  float m = NEG_BIG, l = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load_k = [&](int k0, u32x4 (&ak)[2][DS]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int key = k0 + (j >> 2) * 8 + s * 4 + (j & 3);
+      const u16* kp = kbase + (long)key * D + gq * 8;
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds)
+        ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
+    }
+  };
+  // A = V^T tiles: lane (i = j -> d row, gq) holds keys k0 + gq*8 .. +7 (16 B); loaded one tile ahead like K.
+  // Keys in [k_hi, k0 + 32) read stale-but-finite cache contents (rows are Lmax + 32 long) and get P = 0.
+  auto load_v = [&](int k0, u32x4 (&av)[DT]) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * LV + k0 + gq * 8);
+  };
+  auto tile = [&](int k0, const u32x4 (&ak)[2][DS], const u32x4 (&av)[DT]) {
+    f32x4 st[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) acc = P::mfma(ak[s][ds], bq[ds], acc);
+      st[s] = acc;
+    }
+    const int bfirst = k0 + gq * 8 - prefix;
+    unsigned vbits = 0xffu;
+    if (k0 + 32 > prefix) {
+      if (mask_bits) {
+        const int lo = max(bfirst, 0), wi = lo >> 6;
+        const unsigned long long* mrow = mask_bits + (long)t * mask_words;
+        const unsigned long long w0 = mrow[min(wi, mask_words - 1)], w1 = mrow[min(wi + 1, mask_words - 1)];
+        vbits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int b = bfirst + e;
+          unsigned v = 1u;
+          if (b >= 0) v = (unsigned)((((b >> 6) == wi ? w0 : w1) >> (b & 63)) & 1ull);
+          vbits |= v << e;
+        }
+      } else {
+        vbits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vbits |= (unsigned)(bfirst + e <= t) << e;
+      }
+    }
+    float pv[8];
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = k0 + gq * 8 + e;
+      float sc = st[e >> 2][e & 3] * scale;
+      const bool vis = row_ok && key < k_hi && ((vbits >> e) & 1u);
+      sc = vis ? sc : -INFINITY;
+      pv[e] = sc;
+      tmax = fmaxf(tmax, sc);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __expf(m - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pv[e] = __expf(pv[e] - m_new); psum += pv[e]; }
+    u32x4 pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pb[e] = pack2<P>(pv[2 * e], pv[2 * e + 1]);
+    l = l * alpha + psum;
+    m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      o[dt] *= alpha;
+      o[dt] = P::mfma(av[dt], pb, o[dt]);
+    }
+  };
+
+  u32x4 ka[2][DS], kb2[2][DS], va[DT], vb[DT];
+  const int kstart = k_lo + wv * 32;
+  if (kstart < k_hi) { load_k(kstart, ka); load_v(kstart, va); }
+  for (int k0 = kstart; k0 < k_hi; k0 += 2 * NW * 32) {
+    const int k1 = k0 + NW * 32;
+    const bool two = k1 < k_hi;
+    if (two) { load_k(k1, kb2); load_v(k1, vb); }
+    tile(k0, ka, va);
+    if (two) {
+      if (k1 + NW * 32 < k_hi) { load_k(k1 + NW * 32, ka); load_v(k1 + NW * 32, va); }
+      tile(k1, kb2, vb);
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  // ---- merge the eight wave partials through LDS
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) so[wv][dt][lane] = o[dt];
+  if (gq == 0) { sm[wv][j] = m; sl[wv][j] = l; }
+  __syncthreads();
+  const int nsp = (kv_end + KBK - 1) / KBK;                     // span blocks that did not exit above
+  float M = NEG_BIG, L = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (wv < DT) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wt = __expf(sm[w][j] - M);
+      L += sl[w][j] * wt;
+      acc += so[w][wv][lane] * wt;
+    }
+  }
+  const long orow = (long)t * Hq + hq;
+  if (nsp == 1) {
+    if (wv < DT && row_ok) {
+      const float inv = L > 0.f ? 1.f / L : 0.f;
+      uint2 o2;
+      o2.x = pack2<P>(acc[0] * inv, acc[1] * inv); o2.y = pack2<P>(acc[2] * inv, acc[3] * inv);
+      *reinterpret_cast<uint2*>(out + orow * D + wv * 16 + gq * 4) = o2;
+    }
+    return;
+  }
+  // ---- more than one span: publish (M, L, acc) write-through, last arriver combines
+  const long rows_all = (long)T * Hq;
+  if (wv < DT && row_ok) {
+    const long prow = (long)blockIdx.z * rows_all + orow;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs_o, (int)((prow * D + wv * 16 + gq * 4) * 4), 0, 16);
+    if (wv == 0 && gq == 0) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
+      u32x2 ml = {__float_as_uint(M), __float_as_uint(L)};
+      __builtin_amdgcn_raw_buffer_store_b64(ml, rs_m, (int)(prow * 8), 0, 16);
+    }
+  }
   __shared__ int s_last;
-  const int nsp = (kv_end + chunk - 1) / chunk;                // blocks past kv_end returned above and never arrive
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned* cnt = counters + (long)h * gridDim.y + zq;
+    unsigned* cnt = counters + (long)h * gridDim.y + qt;
     const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (unsigned)(nsp - 1);
     if (last) {
@@ -202,36 +364,21 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
     s_last = last;
   }
   __syncthreads();
-  if (!s_last) return;
-  const long rows_all = (long)T * Hq;
-  for (int qi = 0; qi < qtiles_per_wave; ++qi) {
-    const int qt = (zq * 4 + wv) * qtiles_per_wave + qi;
-    if (qt * 16 >= nrows) break;
-    const int row = qt * 16 + j;
-    if (row >= nrows) continue;
-    const int t = row / g, hq = h * g + row % g;
-    const long r = (long)t * Hq + hq;
-    float M = NEG_BIG;
-    for (int s2 = 0; s2 < nsp; ++s2) M = fmaxf(M, pml[(s2 * rows_all + r) * 2]);
-    float L = 0.f;
-    f32x4 acc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s2 = 0; s2 < nsp; ++s2) {
-      const long pr = s2 * rows_all + r;
-      const float w = __expf(pml[pr * 2] - M);
-      L += pml[pr * 2 + 1] * w;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc[dt] += *reinterpret_cast<const f32x4*>(po + pr * D + dt * 16 + gq * 4) * w;
-    }
-    const float inv = L > 0.f ? 1.f / L : 0.f;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      uint2 o2;
-      o2.x = pack2<P>(acc[dt][0] * inv, acc[dt][1] * inv); o2.y = pack2<P>(acc[dt][2] * inv, acc[dt][3] * inv);
-      *reinterpret_cast<uint2*>(out + r * D + dt * 16 + gq * 4) = o2;
-    }
+  if (!s_last || wv >= DT || !row_ok) return;
+  float Mg = NEG_BIG;
+  for (int s2 = 0; s2 < nsp; ++s2) Mg = fmaxf(Mg, pml[(s2 * rows_all + orow) * 2]);
+  float Lg = 0.f;
+  f32x4 ag = {0.f, 0.f, 0.f, 0.f};
+  for (int s2 = 0; s2 < nsp; ++s2) {
+    const long pr = s2 * rows_all + orow;
+    const float wt = __expf(pml[pr * 2] - Mg);
+    Lg += pml[pr * 2 + 1] * wt;
+    ag += *reinterpret_cast<const f32x4*>(po + pr * D + wv * 16 + gq * 4) * wt;
   }
+  const float inv = Lg > 0.f ? 1.f / Lg : 0.f;
+  uint2 o2;
+  o2.x = pack2<P>(ag[0] * inv, ag[1] * inv); o2.y = pack2<P>(ag[2] * inv, ag[3] * inv);
+  *reinterpret_cast<uint2*>(out + orow * D + wv * 16 + gq * 4) = o2;
 }
 
 // merge the per-split partials: one wave per (t, hq) row
@@ -271,8 +418,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(u16* __restrict__ out
 }
 
 // partial buffers: po  [max_splits][T][Hq][D] fp32, pml [max_splits][T][Hq][2] fp32
-// counters: NULL -> separate combine kernel; else >= Hkv * 64 zeroed uint32 (self-resetting): combine fused into the
-// attention kernel (last-arriving key-split block per (kv head, query group))
+// counters: >= Hkv * ceil(T * (Hq/Hkv) / 16) zeroed uint32 (self-resetting) -> single-launch kernel for any Lmax;
+// NULL -> single launch only if Lmax <= 2048, else key splits + a combine kernel
 extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
                              const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
                              int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
@@ -280,6 +427,27 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
   if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 8 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
   const int nrows = T * (Hq / Hkv);
   const int nqt = (nrows + 15) / 16;
+  // Single-launch kernel: with a counters buffer for any Lmax (spans of 2048 keys, cross-block merge only once the
+  // context outgrows a span); without one only when a single span covers Lmax.  The choice depends on Lmax alone
+  // (kv_end lives on the device), so a captured graph stays valid as the context grows.
+  static const bool no_single = getenv("UMB_ATTN_SPLIT") != nullptr;
+  const int KBK = 2048;
+  const int spans = (Lmax + KBK - 1) / KBK;
+  if ((counters || spans == 1) && nqt <= 65535 && spans <= max_splits && !no_single) {
+    const dim3 grid1(Hkv, nqt, spans), block1(512);
+#define ATT1_(DD)                                                                                                 \
+  hipLaunchKernelGGL((tree_attn1_kernel<P, DD, 8>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,      \
+                     (const u16*)vt_cache, prefix_len, (const unsigned long long*)mask_bits, mask_words,           \
+                     n_mask_keys, T, Hq, Hkv, Lmax, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters)
+    DISPATCH_DTYPE(dtype, {
+      if (D == 128) { ATT1_(128); }
+      else if (D == 64) { ATT1_(64); }
+      else { ATT1_(32); }
+    })
+#undef ATT1_
+    UMB_LAUNCH_CHECK();
+    return UMB_OK;
+  }
   int qpw = 1;
   while ((nqt + 4 * qpw - 1) / (4 * qpw) > 64 && qpw < 8) qpw *= 2;
   const int gz = (nqt + 4 * qpw - 1) / (4 * qpw);
@@ -289,10 +457,9 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
   hipLaunchKernelGGL((tree_attn_kernel<P, DD>), grid, block, 0, st, (const u16*)q, (const u16*)k_cache,            \
                      (const u16*)vt_cache, (float*)po, (float*)pml, prefix_len,                                    \
                      (const unsigned long long*)mask_bits, mask_words, n_mask_keys, T, Hq, Hkv, Lmax, chunk, qpw,  \
-                     scale, counters, (u16*)out);                                                                  \
-  if (!counters)                                                                                                   \
-    hipLaunchKernelGGL((attn_combine_kernel<P, DD>), dim3((rows + 3) / 4), dim3(256), 0, st, (u16*)out,            \
-                       (const float*)po, (const float*)pml, prefix_len, n_mask_keys, chunk, rows)
+                     scale);                                                                                       \
+  hipLaunchKernelGGL((attn_combine_kernel<P, DD>), dim3((rows + 3) / 4), dim3(256), 0, st, (u16*)out,              \
+                     (const float*)po, (const float*)pml, prefix_len, n_mask_keys, chunk, rows)
   DISPATCH_DTYPE(dtype, {
     if (D == 128) { ATT_(128); }
     else if (D == 64) { ATT_(64); }

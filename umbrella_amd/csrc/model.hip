@@ -48,7 +48,7 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
                          m->rope_sin, ws->q, kc, vt, /*paired=*/1, dt, st));
   CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
-                   nullptr, dt, st));
+                   ws->attn_counters, dt, st));
   CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.o, T), T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue

@@ -359,7 +359,9 @@ class Llama(LLMBase):
         maxn = max(N for (N, K, S) in self._plans.values())
         if not hasattr(self, "_counters"):          # self-resetting arrival counters (zero between launches)
             self._counters = torch.zeros(maxn // 64 + 64, dtype=torch.int32, device=dev)
-            self._attn_counters = torch.zeros(c.num_key_value_heads * 64 + 64, dtype=torch.int32, device=dev)
+            g = c.num_attention_heads // c.num_key_value_heads
+            self._attn_counters = torch.zeros(c.num_key_value_heads * ((1024 * g + 15) // 16) + 64, dtype=torch.int32,
+                                              device=dev)      # one per (kv head, 16-row query tile), T <= 1024
         ws = self._ws = UmbWorkspace()
         ws.h, ws.xn, ws.q, ws.attn, ws.act = (w[k].data_ptr() for k in ("h", "xn", "q", "attn", "act"))
         ws.partial, ws.attn_po, ws.attn_ml = w["partial"].data_ptr(), w["po"].data_ptr(), w["ml"].data_ptr()
