@@ -223,6 +223,32 @@ def test_stochastic_graph_equals_eager_and_reseed(dev, kind):
     assert outs[0] == outs[1]
 
 
+def test_measure_acceptance_rate(dev):
+    """Sequoia tooling (examples/construct_sequoia.py of the reference): a model drafting for itself is accepted
+    at rank 0 everywhere; an unrelated draft's counts equal the oracle's rank statistics within near-tie slack."""
+    from hip_helpers import hip_model
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree, measure_acceptance_rate
+    dtype = torch.float16
+    tgt, tsd = hip_model(G["target_cfg"], G["seeds"]["target"], 256, dtype, dev)
+    same, _ = hip_model(G["target_cfg"], G["seeds"]["target"], 256, dtype, dev)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(6, 500, (1, 96), generator=g)
+    counts, n = measure_acceptance_rate(same, tgt, ids, 40, 4)
+    assert n == 40 and counts.cpu().tolist() == [40.0, 0.0, 0.0, 0.0]
+    small, ssd = hip_model(G["draft_cfg"], G["seeds"]["draft"], 256, dtype, dev)
+    counts, n = measure_acceptance_rate(small, tgt, ids, 40, 4)
+    P = ids.shape[1]
+    mask = torch.tril(torch.ones(P, P + 1, dtype=torch.bool))
+    lt = oracle_model(G["target_cfg"], G["seeds"]["target"], P + 1, torch.float32, state=tsd).inference(
+        ids, torch.arange(P)[None], mask, torch.arange(P))[0, P - 41:P - 1]
+    ld = oracle_model(G["draft_cfg"], G["seeds"]["draft"], P + 1, torch.float32, state=ssd).inference(
+        ids, torch.arange(P)[None], mask, torch.arange(P))[0, P - 41:P - 1]
+    exp = (ld.topk(4, dim=-1).indices == lt.argmax(-1)[:, None]).float().sum(0)
+    assert (counts.cpu() - exp).abs().sum() <= 4, (counts, exp)          # fp16 near-ties may move a few ranks
+    gm = generate_sequoia_tree(3, 4, acc=[max(float(c) / n, 1e-6) for c in counts[:3]])
+    assert gm["size"] == 13
+
+
 def test_reference_face_and_awq_linear(dev):
     """AutoEngine / AutoModelLM / AwqLinear keep the reference's contracts."""
     from umbrella_amd.models import AutoModelLM

@@ -74,3 +74,29 @@ def expected_accept_length(growmap: dict, acc) -> float:
         for r, c in enumerate(kids):
             reach[c] = reach[p] * (acc[r] if r < len(acc) else 0.0)
     return sum(reach)
+
+
+def measure_acceptance_rate(draft_model, target_model, input_ids, solution_len: int, width: int):
+    """Acceptance counts of one sequence (examples/construct_sequoia.py:66-90 of the reference): over the last
+    `solution_len` positions, how often the target's arg-max token is the draft's rank-r choice, r < width.
+    Both models run one causal forward over `input_ids` (LongTensor [1, P]); the ranks come from the device
+    top-k / arg-max kernels on the fp32 logits.  Returns (counts float32 [width] on the device, solution_len)."""
+    import torch
+    from . import _lib
+    P = input_ids.shape[1]
+    dev = target_model.device
+    pos = torch.arange(P, device=dev)
+    mask = torch.tril(torch.ones(P, P, dtype=torch.bool, device=dev))
+    lo = P - solution_len - 1
+    counts = torch.zeros(width, dtype=torch.float32, device=dev)
+    lt = target_model.inference(input_ids, pos[None], mask, pos)[0, lo:P - 1].contiguous()
+    V = lt.shape[-1]
+    best = torch.empty(solution_len, dtype=torch.int32, device=dev)
+    _lib.call("umb_argmax_rows", best, lt, solution_len, V)
+    ld = draft_model.inference(input_ids, pos[None], mask, pos)[0, lo:P - 1].contiguous()
+    top = torch.empty(solution_len, width, dtype=torch.int32, device=dev)
+    _lib.call("umb_topk_rows", top, None, ld, solution_len, V, width, None, None, None, None)
+    counts += (top == best[:, None]).float().sum(dim=0)
+    target_model.clear()
+    draft_model.clear()
+    return counts, solution_len
