@@ -85,10 +85,12 @@ int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
  * + KV_Cache.update_kv_cache (umbrella/attn/cache.py:53-65) at slots slot[t].
  * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax + UMB_VT_PAD] (layer base pointers).
- * paired != 0: the q/k rows of the linear were packed as RoPE partner pairs (repack mode 2). */
+ * paired != 0: the q/k rows of the linear were packed as RoPE partner pairs (repack mode 2).
+ * bias: NULL or the fused [q|k|v] projection bias [(Hq + 2 Hkv) D] in the model dtype, HF feature order
+ * (Qwen2: umbrella/models/qwen.py:94-96). */
 int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
                         const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
-                        void* vt_cache, int paired, int dtype, umb_stream_t stream);
+                        void* vt_cache, int paired, const void* bias, int dtype, umb_stream_t stream);
 /* F.embedding (llama.py:124) + per-forward position/slot/prefix resolution.
  * explicit mode: tok/pos/slot/prefix given.  tree mode (tokens_all != NULL):
  * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i.
@@ -161,6 +163,7 @@ typedef struct UmbLayer {
   UmbLinear qkv, o, gu, down;       /* fused [q|k|v], o_proj, fused [gate|up], down_proj */
   const void* norm1;                /* input_layernorm weight [H] */
   const void* norm2;                /* post_attention_layernorm weight [H] */
+  const void* qkv_bias;             /* NULL, or fused [q|k|v] bias (Qwen2), model dtype, HF feature order */
 } UmbLayer;
 
 typedef struct UmbModel {

@@ -107,9 +107,11 @@ class OracleLlama:
     # -- linear: dense F.linear (llama.py:89-91) or AwqLinear.apply (awq_utils.py:63-86)
     def _lin(self, x, name):
         if name + ".qweight" in self.w:
-            return ops.awq_linear(x, self.w[name + ".qweight"], self.w[name + ".qzeros"],
-                                  self.w[name + ".scales"], self.G)
-        return F.linear(x, self.w[name + ".weight"])
+            out = ops.awq_linear(x, self.w[name + ".qweight"], self.w[name + ".qzeros"],
+                                 self.w[name + ".scales"], self.G)
+            b = self.w.get(name + ".bias")
+            return out if b is None else out + b
+        return F.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"))       # bias: qwen.py:94-96
 
     def _layer(self, i, h, position_ids, mask, storage_ids):     # llama.py:75-114 / 262-303
         p = f"model.layers.{i}."

@@ -121,7 +121,7 @@ def test_qkv_rope_kv_append(dev, dtype):
     kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev)
     vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype, device=dev)
     _lib.call("umb_reduce_qkv_rope", part.to(dev), 2, T, Hq, Hkv, D, Lmax, pos.to(dev), slot.to(dev), cos.to(dev),
-              sin.to(dev), q, kc, vt, 0, _lib.dtype_code(dtype))
+              sin.to(dev), q, kc, vt, 0, None, _lib.dtype_code(dtype))
     full = part.sum(0).to(dtype)
     qr, kr, vr = full[:, :Hq * D].view(T, Hq, D), full[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D), full[:, (Hq + Hkv) * D:].view(T, Hkv, D)
     qe, ke = O.apply_rope(qr, kr, cos, sin, pos.long())

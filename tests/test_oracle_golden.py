@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLD, load_golden, oracle_engine_for_case, oracle_model
+from helpers import replay_case, GOLD, load_golden, oracle_engine_for_case, oracle_model
 from oracle import ops, sequoia
 from oracle.model import AppendKV, SlotKV
 
@@ -80,46 +80,7 @@ def test_model_logits_match_reference():
 
 
 def _replay(case_name):
-    case = G["cases"][case_name]
-    eng = oracle_engine_for_case(G, case_name)
-    ok = eng._prefill(torch.tensor([case["prompt"]]))
-    assert ok == case["prefill_ok"]
-    if not ok:
-        return
-    assert int(eng.tokens[0, eng.num_nodes]) == case["first_token"]
-    it_iter = iter(case["iters"])
-
-    def loop(turn):
-        start, go, steps = eng.num_nodes, True, 0
-        while go and (eng.num_nodes - start) < case["max_new_tokens"] and eng.validate_status():
-            n = eng.num_nodes
-            eng.build_tree()
-            rec = next(it_iter)
-            assert rec["n"] == n
-            assert eng.tokens[0, n:n + eng.tree_size].tolist() == rec["tree_tokens"], (case_name, steps)
-            assert eng.parents.tolist() == rec["parents"]
-            if "tree_score" in rec:
-                np.testing.assert_allclose(eng.tree_score.numpy(), np.array(rec["tree_score"]), rtol=1e-4, atol=1e-5)
-                cur = eng.cur
-                assert eng.mask_iter[n:cur, n:cur].sum(-1).tolist() == rec["tree_mask_rowsum"]
-            go = eng.verify()
-            assert eng.num_nodes == rec["num_nodes"] and go == rec["go_on"]
-            assert int(eng.tokens[0, eng.num_nodes]) == rec["bonus"]
-            assert eng.target_model.kv_cache.kv_offset == rec["target_kv"]
-            assert eng.draft_model.kv_cache.kv_offset == rec["draft_kv"]
-            steps += 1
-        assert eng.tokens[0, start:eng.num_nodes + 1].tolist() == turn["tokens"]
-        assert steps == turn["steps"]
-
-    loop(case["turns"][0])
-    if "append" in case:
-        assert eng._append(torch.tensor([case["append"]])) == case["append_ok"]
-        assert int(eng.tokens[0, eng.num_nodes]) == case["append_first_token"]
-        loop(case["turns"][1])
-    eng.reset()
-    toks, acc = eng.generate_ids(case["prompt"], case["max_new_tokens"])
-    assert toks == case["generate"]["generated_tokens"]
-    assert abs(acc - case["generate"]["avg_accept_tokens"]) < 1e-9
+    replay_case(G["cases"][case_name], oracle_engine_for_case(G, case_name), case_name)
 
 
 @pytest.mark.parametrize("case", sorted(G["cases"].keys()))

@@ -31,7 +31,7 @@ class UmbLinear(C.Structure):
 
 class UmbLayer(C.Structure):
     _fields_ = [("qkv", UmbLinear), ("o", UmbLinear), ("gu", UmbLinear), ("down", UmbLinear),
-                ("norm1", C.c_void_p), ("norm2", C.c_void_p)]
+                ("norm1", C.c_void_p), ("norm2", C.c_void_p), ("qkv_bias", C.c_void_p)]
 
 
 class UmbModel(C.Structure):
@@ -85,7 +85,7 @@ SIGNATURES = {
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],
     "umb_reduce_residual_norm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P],
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
-    "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "umb_embed_prep": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "umb_tree_attn": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "umb_argmax_rows": [_P, _P, _I, _I, _P],

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
                                                              const int* __restrict__ slot,
                                                              const u16* __restrict__ cosT, const u16* __restrict__ sinT,
                                                              u16* __restrict__ q_out, u16* __restrict__ kc,
-                                                             u16* __restrict__ vt, int paired) {
+                                                             u16* __restrict__ vt, int paired,
+                                                             const u16* __restrict__ bias) {
   const int t = blockIdx.x, head = blockIdx.y;             // head in [0, Hq + 2*Hkv)
   const int N = (Hq + 2 * Hkv) * D;
   const int half = D / 2;
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
     const int ca = pr ? 2 * d : d, cb = pr ? 2 * d + 1 : d + half;
     float a = base[ca], b = base[cb];
     for (int s = 1; s < S; ++s) { a += base[s * sstride + ca]; b += base[s * sstride + cb]; }
+    if (bias) {        // F.linear(x, W, b) (qwen.py:94-96): bias joins the fp32 accumulator, one rounding; HF feature order
+      a += P::to_f(bias[head * D + d]); b += P::to_f(bias[head * D + d + half]);
+    }
     a = rnd<P>(a); b = rnd<P>(b);
     if (head < Hq + Hkv) {
       // rotate-half RoPE in the model dtype (each product and the sum are rounded, as eager torch does)
@@ -246,12 +250,13 @@ extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, voi
 
 extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax,
                                    const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
-                                   void* k_cache, void* vt_cache, int paired, int dtype, hipStream_t st) {
+                                   void* k_cache, void* vt_cache, int paired, const void* bias, int dtype,
+                                   hipStream_t st) {
   if (D % 2) return UMB_EINVAL;
   DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
                        Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
-                       (u16*)vt_cache, paired);
+                       (u16*)vt_cache, paired, (const u16*)bias);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;

@@ -45,7 +45,7 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
   CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, nullptr));
   CK(umb_reduce_qkv_rope(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
-                         m->rope_sin, ws->q, kc, vt, /*paired=*/1, dt, st));
+                         m->rope_sin, ws->q, kc, vt, /*paired=*/1, ly.qkv_bias, dt, st));
   CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
                    ws->attn_counters, dt, st));
@@ -67,6 +67,7 @@ static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
+  if (ly.qkv_bias) return UMB_EINVAL;          // projection bias: default schedule only
   UmbGemmFused fx = {};
   // 1. qkv GEMM -> (last split block) 1/rms, RoPE at tree positions, q out, K/V appended at their slots
   fx.ssq_in = ws->ssq; fx.ssq_groups = ws->ssq_stride; fx.ssq_dim = (float)m->H; fx.eps = m->eps;

@@ -1,8 +1,9 @@
 """AutoModelLM (umbrella/models/auto_model.py:157-182): name -> runtime.
 
 The reference keeps three hub-id dicts (plain / offload / cudagraph) of near-identical
-classes; here one HIP-backed ``Llama`` takes ``offload`` / ``cuda_graph`` flags.
-Accepted names: the Llama hub ids the reference registers (dims tabulated in
+classes; here one HIP-backed ``Llama`` runtime takes ``offload`` / ``cuda_graph`` flags and covers the reference's Llama,
+Qwen (q/k/v projection bias, umbrella/models/qwen.py:94-96) and Mistral (free head_dim, mistral.py:28,101) classes.
+Accepted names: the Llama, Qwen2.5 / QwQ and Mistral hub ids the reference registers (dims tabulated in
 models/config.py -- weights are read from a local HF directory when given one, else
 seeded synthetic tensors of the exact shapes), or a local directory with config.json.
 """

@@ -39,6 +39,7 @@ class LlamaCfg:
     awq: bool = False                 # 4-bit AWQ (GEMM format, group 128, zero point)
     awq_group: int = 128
     name: str = "llama"
+    attention_bias: bool = False      # q/k/v projection bias (Qwen2: umbrella/models/qwen.py:94-96)
 
     @property
     def q_dim(self):
@@ -60,7 +61,10 @@ class LlamaCfg:
             with open(gen) as f:
                 eos = json.load(f).get("eos_token_id", eos)
         q = c.get("quantization_config") or {}
-        return cls(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+        qwen = c.get("model_type") == "qwen2"
+        if qwen:                                    # the reference pins Qwen2.5's vocabulary (qwen.py:12,27)
+            c["vocab_size"] = min(c["vocab_size"], 151936)
+        return cls(attention_bias=bool(c.get("attention_bias", qwen)), vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
                    intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
                    num_attention_heads=c["num_attention_heads"],
                    num_key_value_heads=c.get("num_key_value_heads", c["num_attention_heads"]),
@@ -96,6 +100,40 @@ KNOWN = {
         num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8, head_dim=128,
         rope_scaling=LLAMA31_ROPE, awq=True, name="llama-3.3-70b-awq"),
 }
+
+
+def _qwen(H, I, L, Hq, Hkv, tie, awq=False, name="qwen2.5"):
+    return LlamaCfg(vocab_size=151936, hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=Hq,
+                    num_key_value_heads=Hkv, head_dim=128 if H != 896 else 64, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                    rope_scaling=None, max_position_embeddings=32768, tie_word_embeddings=tie,
+                    eos_token_id=[151645, 151643], awq=awq, attention_bias=True, name=name)
+
+
+# Qwen2.5 / Mistral families the reference registers (auto_model.py:21-55, 80-154): public HF dims.
+_QWEN_DIMS = {"0.5B": (896, 4864, 24, 14, 2, True), "1.5B": (1536, 8960, 28, 12, 2, True),
+              "3B": (2048, 11008, 36, 16, 2, True), "7B": (3584, 18944, 28, 28, 4, False),
+              "14B": (5120, 13824, 48, 40, 8, False), "32B": (5120, 27648, 64, 40, 8, False),
+              "72B": (8192, 29568, 80, 64, 8, False)}
+for _size, _d in _QWEN_DIMS.items():
+    for _stem in ("Qwen/Qwen2.5-", "Qwen/Qwen2.5-Coder-"):
+        KNOWN[f"{_stem}{_size}-Instruct"] = _qwen(*_d, name=f"qwen2.5-{_size.lower()}")
+        KNOWN[f"{_stem}{_size}-Instruct-AWQ"] = _qwen(*_d, awq=True, name=f"qwen2.5-{_size.lower()}-awq")
+KNOWN["Qwen/QwQ-32B-Preview"] = _qwen(*_QWEN_DIMS["32B"], name="qwq-32b")
+KNOWN["KirillR/QwQ-32B-Preview-AWQ"] = _qwen(*_QWEN_DIMS["32B"], awq=True, name="qwq-32b-awq")
+KNOWN["casperhansen/deepseek-r1-distill-qwen-32b-awq"] = _qwen(*_QWEN_DIMS["32B"], awq=True, name="r1-distill-qwen-32b-awq")
+
+
+def _mistral(V, H, I, L, theta, awq=False, name="mistral"):
+    return LlamaCfg(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=32,
+                    num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-5, rope_theta=theta, rope_scaling=None,
+                    max_position_embeddings=32768, tie_word_embeddings=False, eos_token_id=[2], awq=awq, name=name)
+
+
+KNOWN["mistralai/Mistral-7B-Instruct-v0.3"] = _mistral(32768, 4096, 14336, 32, 1000000.0, name="mistral-7b-v0.3")
+KNOWN["solidrust/Mistral-7B-Instruct-v0.3-AWQ"] = _mistral(32768, 4096, 14336, 32, 1000000.0, awq=True, name="mistral-7b-v0.3-awq")
+# head_dim 128 with hidden 5120: attention width Hq*D = 4096 != hidden (mistral.py:28,101)
+KNOWN["mistralai/Mistral-Small-24B-Instruct-2501"] = _mistral(131072, 5120, 32768, 40, 100000000.0, name="mistral-small-24b")
+KNOWN["stelterlab/Mistral-Small-24B-Instruct-2501-AWQ"] = _mistral(131072, 5120, 32768, 40, 100000000.0, awq=True, name="mistral-small-24b-awq")
 KNOWN["meta-llama/Llama-3.2-1B"] = KNOWN["meta-llama/Llama-3.2-1B-Instruct"]
 KNOWN["meta-llama/Meta-Llama-3.1-8B-Instruct"] = KNOWN["meta-llama/Llama-3.1-8B-Instruct"]
 

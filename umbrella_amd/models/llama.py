@@ -142,6 +142,8 @@ class Llama(LLMBase):
             raise ValueError(f"Model type '{model_name}' is not supported. Supported types: {list(KNOWN.keys())} "
                              "or a local directory with config.json")
         c = self.config
+        if c.attention_bias:
+            self.fused = False                    # projection bias lives in the default schedule's reduce kernel
         self.hidden_size, self.num_heads, self.head_dim = c.hidden_size, c.num_attention_heads, c.head_dim
         self.num_key_value_heads = c.num_key_value_heads
         self.eos_tokens = list(c.eos_token_id)
@@ -179,6 +181,8 @@ class Llama(LLMBase):
         def synth(name, shape, kind):
             if kind == "norm":
                 return torch.ones(shape, dtype=self.dtype, device=dev)
+            if kind == "bias":
+                return synth_tensor(shape, 0.1, self.dtype, dev, gen)
             if kind == "embed":
                 return synth_tensor(shape, 1.0, self.dtype, dev, gen)
             std = 0.02 if kind == "linear" else 0.05
@@ -259,7 +263,7 @@ class Llama(LLMBase):
             wb, mb = PackedLinear.packed_bytes(sum(shapes[n][0] for n in names), shapes[names[0]][1], c.awq)
             slab_bytes += wb + mb
         self.slab_bytes = slab_bytes
-        self.layers, self.slabs, self.host_slabs, self.norms = [], [], [], []
+        self.layers, self.slabs, self.host_slabs, self.norms, self.qkv_biases = [], [], [], [], []
         self._layer_structs = (UmbLayer * L)()
         stream_any = False
         for i in range(L):
@@ -273,6 +277,11 @@ class Llama(LLMBase):
             n1 = fetch(p + "input_layernorm.weight", (H,), "norm").to(dt).contiguous()
             n2 = fetch(p + "post_attention_layernorm.weight", (H,), "norm").to(dt).contiguous()
             self.norms.append((n1, n2))
+            qb = None
+            if c.attention_bias:
+                qb = torch.cat([fetch(p + f"self_attn.{n}.bias", (shapes[f"self_attn.{n}"][0],), "bias").to(dt).reshape(-1)
+                                for n in ("q_proj", "k_proj", "v_proj")]).contiguous()
+            self.qkv_biases.append(qb)
             streamed = self.offload and i >= self.num_cache_layers
             ls = self._layer_structs[i]
             for key in ("qkv", "o", "gu", "down"):
@@ -282,6 +291,7 @@ class Llama(LLMBase):
                 else:
                     setattr(ls, key, ln.struct())
             ls.norm1, ls.norm2 = n1.data_ptr(), n2.data_ptr()
+            ls.qkv_bias = qb.data_ptr() if qb is not None else None
             if streamed:
                 host = torch.empty(slab_bytes, dtype=torch.uint8, pin_memory=True)
                 host.copy_(slab)

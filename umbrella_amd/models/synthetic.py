@@ -45,6 +45,11 @@ def synth_state_small(cfg: LlamaCfg, seed: int, std: float = 0.06) -> dict:
     sd["model.norm.weight"] = 1.0 + nrm(cfg.hidden_size, s=0.1)
     if not cfg.tie_word_embeddings:
         sd["lm_head.weight"] = nrm(cfg.vocab_size, cfg.hidden_size, s=0.3)
+    if getattr(cfg, "attention_bias", False):          # drawn last: bias-free fixtures keep their stream
+        for i in range(cfg.num_hidden_layers):
+            for name in ("q_proj", "k_proj", "v_proj"):
+                n = linear_shapes(cfg)["self_attn." + name][0]
+                sd[f"model.layers.{i}.self_attn.{name}.bias"] = nrm(n, s=0.5)
     return sd
 
 
