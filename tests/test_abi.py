@@ -34,7 +34,7 @@ def test_struct_layouts_match_header(lib):
     import ctypes as C
     from umbrella_amd import _lib
     assert C.sizeof(_lib.UmbLinear) == 40
-    assert C.sizeof(_lib.UmbLayer) == 4 * 40 + 16
+    assert C.sizeof(_lib.UmbLayer) == 4 * 40 + 24
     assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 40 + 6 * 8
     assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
     assert C.sizeof(_lib.UmbGemmFused) == 144
