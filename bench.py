@@ -270,8 +270,16 @@ def main():
         n_mid = start + tokens / world / 2
         kv_t = m.num_layers * 2 * m.config.num_key_value_heads * m.config.head_dim * 2
         kv_d = d.num_layers * 2 * d.config.num_key_value_heads * d.config.head_dim * 2
-        draft_fwd = d.weight_bytes() - (d.lm_head.N * d.lm_head.K * 2) / len(levels)     # last level skips lm_head
-        bytes_iter = len(levels) * draft_fwd + m.weight_bytes() + n_mid * (kv_t + len(levels) * kv_d)
+        # draft forwards actually executed per iteration: one per expanded level (the reference's extra KV-fill
+        # forward over the deepest level is folded into the next root forward, engine_common._draft_root), each
+        # with its lm_head; without the look-back the reference count (len(levels), last one without lm_head)
+        if getattr(eng, "lookback", False):
+            n_fwd = len(levels) - 1
+            draft_fwd = d.weight_bytes()
+        else:
+            n_fwd = len(levels)
+            draft_fwd = d.weight_bytes() - (d.lm_head.N * d.lm_head.K * 2) / len(levels)
+        bytes_iter = n_fwd * draft_fwd + m.weight_bytes() + n_mid * (kv_t + n_fwd * kv_d)
         iter_ms = dt / args.steps * 1e3
         out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(value, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(iter_ms, 4),
@@ -283,7 +291,7 @@ def main():
                           "parallelism": "1 engine per GPU (replicas)" if world > 1 else "single GPU"},
                "accept_len": round(accept_len, 3), "value_raw_draft": round(raw_tps, 2),
                "accept_len_raw_draft": round(raw_accept, 3), "oracle_draft_divergence": getattr(eng, "diverged", 0), "oracle_draft_passes": passes,
-               "iter_bytes_GB": round(bytes_iter / 1e9, 3),
+               "draft_forwards_per_iter": n_fwd, "iter_bytes_GB": round(bytes_iter / 1e9, 3),
                "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_roofline:
             kr = kernel_roofline(eng)

@@ -58,8 +58,13 @@ class DynamicSpeculationEngine(HipEngine):
             w = W if step > 0 else 1
             off = 0 if step == 0 else 1 + (step - 1) * W
             last = step == self.tree_depth                          # last forward only fills the draft KV (dynamic:218,235)
-            d.forward_tree(self.tokens, self.n_dev, self.depth, off, w, self.mask_bits, self.mask_words,
-                           head_from=w if last else 0)
+            if last and self.lookback:
+                break                                               # re-derived by the next root forward (_draft_root)
+            if step == 0:
+                self._draft_root()
+            else:
+                d.forward_tree(self.tokens, self.n_dev, self.depth, off, w, self.mask_bits, self.mask_words,
+                               head_from=w if last else 0)
             if last:
                 break
             _lib.call("umb_topk_rows", self.top_idx, self.top_val, d.logits_buffer, w, self.vocab_size, B,

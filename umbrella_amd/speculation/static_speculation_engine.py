@@ -116,10 +116,15 @@ class StaticSpeculationEngine(HipEngine):
     @torch.inference_mode()
     def build_tree(self):
         d = self.draft_model
-        for lv in self.levels:
+        for li, lv in enumerate(self.levels):
             has_head = lv["k"] > 0
-            d.forward_tree(self.tokens, self.n_dev, self.depth, lv["off"], lv["w"], self.mask_bits, self.mask_words,
-                           head_from=0 if has_head else lv["w"])
+            if not has_head and self.lookback:
+                continue                              # deepest level: its draft KV is re-derived by the next root forward
+            if li == 0:
+                self._draft_root()
+            else:
+                d.forward_tree(self.tokens, self.n_dev, self.depth, lv["off"], lv["w"], self.mask_bits,
+                               self.mask_words, head_from=0 if has_head else lv["w"])
             if has_head:
                 _lib.call("umb_topk_rows", None, None, d.logits_buffer, lv["w"], self.vocab_size, lv["k"],
                           self.tokens, self.n_dev, lv["child_start"], lv["child_cnt"])
