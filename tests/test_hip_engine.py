@@ -223,6 +223,33 @@ def test_stochastic_graph_equals_eager_and_reseed(dev, kind):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+def test_draft_lookback_matches_reference_schedule(dev, kind, monkeypatch):
+    """Dropping the per-iteration KV-fill draft forward (the next root forward re-derives slot n-1) leaves the
+    draft's KV cache, the trees it proposes and the accepted tokens unchanged w.r.t. the reference schedule."""
+    from hip_helpers import dynamic_engine, static_engine
+    dtype = torch.float16
+    res = {}
+    for lb in ("1", "0"):
+        monkeypatch.setenv("UMB_DRAFT_LOOKBACK", lb)
+        if kind == "static":
+            eng, _ = static_engine(G, dev, dtype, self_draft=False)
+        else:
+            eng, _ = dynamic_engine(G, dev, dtype, self_draft=False, width=4, num_beams=6, depth=3)
+        assert eng.lookback == (lb == "1")
+        assert eng._prefill(torch.tensor([PROMPT]))
+        accepts = []
+        for _ in range(10):
+            eng.step()
+            accepts.append(eng.last_accept)
+        n = eng.num_nodes
+        kv = eng.draft_model.kv_cache
+        res[lb] = (eng.tokens[:n + 1].tolist(), accepts, kv.k[:, :, :n].float().cpu(), kv.vt[:, :, :, :n].float().cpu())
+    assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
+    for a, b in zip(res["1"][2:], res["0"][2:]):
+        assert (a - b).abs().max() <= 2e-2 * b.abs().max()       # same keys up to attention summation order
+
+
 def test_measure_acceptance_rate(dev):
     """Sequoia tooling (examples/construct_sequoia.py of the reference): a model drafting for itself is accepted
     at rank 0 everywhere; an unrelated draft's counts equal the oracle's rank statistics within near-tie slack."""
