@@ -97,10 +97,11 @@ class PipelinedTarget:
         self.m, self.comm, self.eng = stage_model, comm, engine
         self.config, self.max_length, self.eos_tokens = stage_model.config, stage_model.max_length, stage_model.eos_tokens
         self.kv_cache, self.CHUNK, self.num_layers = stage_model.kv_cache, stage_model.CHUNK, stage_model.num_layers
+        self.PREFILL_CHUNK = self.CHUNK          # activations travel in CHUNK-row messages (PipelineComm buffers)
         self._off = None
 
-    def reserve(self, tokens):
-        self.m.reserve(tokens)
+    def reserve(self, tokens, logit_rows=None):
+        self.m.reserve(tokens, logit_rows)
 
     def clear(self):
         self.comm.command(OP_RESET)

@@ -98,8 +98,10 @@ class HipEngine(BaseEngine):
         self.root_mask = torch.zeros(2, self.mask_words, dtype=torch.int64, device=dev)
         self.root_mask[1, 0] = 1
         self.rng_state = torch.tensor([self.seed], dtype=torch.int64, device=dev)    # device-resident: reseed without recapture
-        self.draft_model.reserve(max(self.draft_model.CHUNK, self.draft_rows))
-        self.target_model.reserve(max(self.target_model.CHUNK, tree_size))
+        # final workspace sizes before any graph capture: wide prompt chunks, logits only for tree rows
+        for mdl, rows in ((self.draft_model, max(self.draft_rows, 2)), (self.target_model, tree_size)):
+            rows = max(mdl.CHUNK, rows)
+            mdl.reserve(max(mdl.PREFILL_CHUNK, rows), logit_rows=rows)
 
     # ------------------------------------------------------------------ text API
     def prefill(self, text: str):
