@@ -250,6 +250,57 @@ def test_draft_lookback_matches_reference_schedule(dev, kind, monkeypatch):
         assert (a - b).abs().max() <= 2e-2 * b.abs().max()       # same keys up to attention summation order
 
 
+def test_static_engine_wide_tree_multiword_mask(dev):
+    """A 129-node growmap (16 x 8): the ancestor mask spans three 64-bit words and the verify runs through the
+    T > 64 kernels; output must still be the fp32 oracle target's greedy continuation."""
+    from hip_helpers import check_greedy, static_engine
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree
+    dtype = torch.float16
+    gm = generate_sequoia_tree(16, 8, acc=[0.4, 0.2, 0.1, 0.08, 0.06, 0.05, 0.04, 0.03, 0.02, 0.01, 0.005, 0.003,
+                                             0.001, 0.0005, 0.0002, 0.0001])
+    assert gm["size"] == 129
+    import json, os, tempfile
+    path = os.path.join(tempfile.mkdtemp(), "g.json")
+    with open(path, "w") as f:
+        json.dump(gm, f)
+    from umbrella_amd.models.config import LlamaCfg
+    from umbrella_amd.models.llama import Llama
+    from umbrella_amd.models.synthetic import synth_state_small
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    cfg = LlamaCfg(**dict(G["target_cfg"], eos_token_id=[3, 5]))
+    sd = synth_state_small(cfg, G["seeds"]["target"])
+    models = []
+    for cg in (True, False):
+        m = Llama("tiny", max_length=512, device=str(dev), dtype=dtype, state_dict=sd, config=cfg, cuda_graph=cg)
+        m.alloc()
+        models.append(m)
+    eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap_path=path, max_length=512,
+                                  safe_buffer=16, stop_distance=8, draft_model_obj=models[0],
+                                  target_model_obj=models[1], tokenizer=IdTokenizer())
+    eng.initialize()
+    assert eng.mask_words == 3
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=60)
+    check_greedy(G, sd, PROMPT, out["generated_tokens"], dtype)
+    assert out["avg_accept_tokens"] > 4.0                      # self-draft: deep acceptance along the tree
+
+
+def test_generation_stops_at_context_limit(dev):
+    """Decoding up to the context limit: the loop ends through validate_status (num_nodes > Lmax - safe_buffer),
+    never writes past the buffers, and a following request on the same engine is unaffected (static:414-434)."""
+    from hip_helpers import check_greedy, static_engine
+    dtype = torch.float16
+    eng, sd = static_engine(G, dev, dtype, self_draft=True, max_length=96, safe_buffer=16)
+    out = eng.generate(input_ids=PROMPT, max_new_tokens=1000)
+    n = len(PROMPT) + len(out["generated_tokens"])
+    assert 96 - 16 - 13 <= n - 1 <= 96 - 16 + 13, n
+    check_greedy(G, sd, PROMPT, out["generated_tokens"], dtype)
+    again = eng.generate(input_ids=PROMPT, max_new_tokens=12)["generated_tokens"]
+    assert again[:12] == out["generated_tokens"][:12]
+    assert eng._prefill(torch.tensor([list(range(6, 6 + 70))])) is False        # would overflow -> False, no raise
+    assert eng.generate(input_ids=[], max_new_tokens=8)["generated_tokens"] == []
+
+
 def test_measure_acceptance_rate(dev):
     """Sequoia tooling (examples/construct_sequoia.py of the reference): a model drafting for itself is accepted
     at rank 0 everywhere; an unrelated draft's counts equal the oracle's rank statistics within near-tie slack."""
