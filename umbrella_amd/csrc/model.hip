@@ -34,7 +34,7 @@ static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
                         ws->hw, first_norm, ws->ssq, ws->ssq_stride, m->dtype, st);
 }
 
-// Schedule 0 (default): one decoder layer = 9 launches; split-K partials are reduced at kernel boundaries by
+// Schedule 0 (default): one decoder layer = 8 launches; split-K partials are reduced at kernel boundaries by
 // small epilogue kernels.  Measured faster on MI355X than schedule 1: an in-kernel cross-workgroup hand-off costs
 // as much as a kernel boundary on the 8-XCD part (profiles/README.md), and it serialises a tail onto every GEMM.
 static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,

@@ -131,7 +131,7 @@ class Llama(LLMBase):
         self.max_length = (max_length + 31) // 32 * 32
         self.offload, self.cuda_graph = offload, cuda_graph
         self._state, self._seed = state_dict, seed
-        # layer schedule: False = 9 launches / layer with kernel-boundary split-K reduces (fastest measured),
+        # layer schedule: False = 8 launches / layer with kernel-boundary split-K reduces (fastest measured),
         # True = 5 launches / layer with in-kernel last-arriver reduces (see csrc/model.hip)
         self.fused = os.environ.get("UMB_FUSED", "0") == "1"
         if config is not None:
