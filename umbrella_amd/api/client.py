@@ -1,34 +1,51 @@
-"""Client side of the wire API (umbrella/api/client.py:7-35)."""
+"""Blocking client of the wire API.
+
+Same surface as the reference client (umbrella/api/client.py): ``APIClient(port, host).run()``, then
+``get_output(**generate_kwargs) -> dict`` per request and ``close()``; also usable as a context manager."""
 import socket
 import time
 
 from ..logging_config import setup_logger
 from ..utils import TextColors
-from .api_utils import receive_data, send_data
+from . import api_utils
 
-logger = setup_logger()
+_log = setup_logger()
+
+
+def _dial(host: str, port: int, pause: float) -> socket.socket:
+    """Keep trying until the server accepts (it may still be loading a model)."""
+    attempt = 0
+    while True:
+        attempt += 1
+        try:
+            return socket.create_connection((host, port))
+        except ConnectionRefusedError:
+            _log.info(TextColors.colorize(f"attempt {attempt}: {host}:{port} not accepting yet", "red"))
+            time.sleep(pause)
 
 
 class APIClient:
     def __init__(self, port: int, host: str = "127.0.0.1", retry_seconds: float = 5.0):
-        self.port, self.host, self.retry_seconds = port, host, retry_seconds
+        self.host, self.port, self.retry_seconds = host, port, retry_seconds
+        self.client_socket = None
 
     def run(self):
-        self.client_socket = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        while True:
-            try:
-                self.client_socket.connect((self.host, self.port))
-                break
-            except ConnectionRefusedError:
-                logger.info(TextColors.colorize("Server is not available, retrying...", "red"))
-                time.sleep(self.retry_seconds)
-        hello = receive_data(self.client_socket)
-        logger.info(TextColors.colorize(f"Server confirmation: {hello}", "cyan"))
+        self.client_socket = _dial(self.host, self.port, self.retry_seconds)
+        greeting = api_utils.receive_data(self.client_socket)      # the server greets every new connection
+        _log.info(TextColors.colorize(f"connected: {greeting}", "cyan"))
+        return greeting
 
     def get_output(self, **api_args):
-        send_data(self.client_socket, api_args)
-        return receive_data(self.client_socket)
+        api_utils.send_data(self.client_socket, api_args)
+        return api_utils.receive_data(self.client_socket)
 
     def close(self):
-        send_data(self.client_socket, {"terminate": True})
-        self.client_socket.close()
+        sock, self.client_socket = self.client_socket, None
+        if sock is not None:
+            api_utils.send_data(sock, {"terminate": True})
+            sock.close()
+
+    __enter__ = lambda self: (self.run(), self)[1]                  # noqa: E731
+
+    def __exit__(self, *exc):
+        self.close()

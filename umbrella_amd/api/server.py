@@ -1,74 +1,83 @@
-"""Single-engine TCP server (umbrella/api/server.py:11-74): accept loop, one reader thread per
-client, one worker draining a queue -- the engine is not thread-safe and serves one request at a time."""
+"""Single-engine TCP front end (surface of umbrella/api/server.py: APIServer(config, device, port, max_client).run()).
+
+The engine serves one request at a time: reader threads (one per client) only enqueue requests, a single worker
+thread owns the engine and answers them in arrival order."""
+import queue
 import socket
 import threading
-from queue import Queue
 
 from ..logging_config import setup_logger
-from ..speculation.auto_engine import AutoEngine
 from ..utils import TextColors
 from .api_utils import receive_data, send_data
 
-logger = setup_logger()
+_log = setup_logger()
+_GREETING = {"status": "connected", "message": "Welcome to the server!"}
 
 
 class APIServer:
     def __init__(self, config, device: str = "cuda:0", port: int = 65432, max_client: int = 4, host: str = "127.0.0.1",
                  engine=None):
-        self.port, self.max_client, self.host, self.device, self.config = port, max_client, host, device, config
-        self.engine = engine                      # tests may inject a ready engine
-        self._stop = threading.Event()
+        self.config, self.device = config, device
+        self.host, self.port, self.max_client = host, port, max_client
+        self.engine = engine                      # a ready engine may be injected (tests)
+        self.message_queue: queue.Queue = queue.Queue()
+        self.queue_lock = threading.Lock()
+        self._closing = threading.Event()
+        self.server_socket = None
 
+    # -- per-client reader -------------------------------------------------------------------------------
     def handle_client(self, conn, addr):
-        logger.info(TextColors.colorize(f"Connection from {addr}", "cyan"))
-        try:
-            send_data(conn, {"status": "connected", "message": "Welcome to the server!"})
-            while True:
+        _log.info(TextColors.colorize(f"client {addr} connected", "cyan"))
+        with conn:
+            send_data(conn, _GREETING)
+            while not self._closing.is_set():
                 try:
-                    msg = receive_data(conn)
-                    if msg.get("terminate", False):
-                        break
-                    self.message_queue.put((addr, conn, msg))
-                except Exception as e:
-                    logger.error(TextColors.colorize(f"Error handling data from {addr}: {e}", "red"))
+                    request = receive_data(conn)
+                except Exception as err:          # closed socket / bad frame: drop this client only
+                    _log.error(TextColors.colorize(f"client {addr}: {err}", "red"))
                     break
-        finally:
-            conn.close()
-            logger.info(TextColors.colorize(f"Connection with {addr} closed", "cyan"))
+                if request.get("terminate", False):
+                    break
+                self.message_queue.put((addr, conn, request))
+        _log.info(TextColors.colorize(f"client {addr} disconnected", "cyan"))
 
+    # -- the only thread that touches the engine ------------------------------------------------------------
     def process_queue(self):
         while True:
-            addr, conn, message = self.message_queue.get()
+            addr, conn, request = self.message_queue.get()
             with self.queue_lock:
-                output = self.engine.generate(**message)
-                reply = {**output, "processed": True, "response": "Processed successfully"}
-                try:
-                    send_data(conn, reply)
-                except Exception as e:
-                    logger.error(TextColors.colorize(f"Error sending data to {addr}: {e}", "red"))
+                answer = dict(self.engine.generate(**request), processed=True, response="Processed successfully")
+            try:
+                send_data(conn, answer)
+            except Exception as err:
+                _log.error(TextColors.colorize(f"reply to {addr} failed: {err}", "red"))
 
-    def run(self):
+    def _ensure_engine(self):
         if self.engine is None:
+            from ..speculation.auto_engine import AutoEngine
             self.engine = AutoEngine.from_config(self.device, **self.config)
             self.engine.initialize()
-        self.server_socket = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        self.server_socket.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        self.server_socket.bind((self.host, self.port))
-        self.server_socket.listen(self.max_client)
-        logger.info(TextColors.colorize("umbrella_amd LLM server started successfully", "cyan"))
-        self.message_queue = Queue()
-        self.queue_lock = threading.Lock()
-        threading.Thread(target=self.process_queue, daemon=True).start()
-        while not self._stop.is_set():
+
+    def run(self):
+        self._ensure_engine()
+        listener = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        listener.bind((self.host, self.port))
+        listener.listen(self.max_client)
+        self.server_socket = listener
+        threading.Thread(target=self.process_queue, daemon=True, name="umb-engine-worker").start()
+        _log.info(TextColors.colorize(f"umbrella_amd server listening on {self.host}:{self.port}", "cyan"))
+        while not self._closing.is_set():
             try:
-                conn, addr = self.server_socket.accept()
-            except OSError:
+                conn, addr = listener.accept()
+            except OSError:                       # listener closed by shutdown()
                 break
             threading.Thread(target=self.handle_client, args=(conn, addr), daemon=True).start()
 
     def shutdown(self):
-        self._stop.set()
-        try:
-            self.server_socket.close()
-        except Exception:
-            pass
+        self._closing.set()
+        if self.server_socket is not None:
+            try:
+                self.server_socket.close()
+            except OSError:
+                pass

@@ -772,7 +772,8 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
   const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
   int tdone = 0;
   if constexpr (AWQ != 1) {
-    if (T > 64 && N % 128 == 0 && epi <= EPI_SILU && getenv("UMB_NO_VGEMM") == nullptr) {
+    static const bool no_vgemm = getenv("UMB_NO_VGEMM") != nullptr;     // diagnostic: 64-token chunks only
+    if (T > 64 && N % 128 == 0 && epi <= EPI_SILU && !no_vgemm) {
       const int rem = T % 128;
       tdone = (rem == 0 || rem > 64) ? T : T - rem;                  // a tail of <= 64 tokens is HBM-bound: skinny kernel
       const int rc = launch_verify<P, AWQ>(wp, meta, x, ldx, out, T, tdone, N, K, S, epi, fx0, st);

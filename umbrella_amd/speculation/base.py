@@ -1,46 +1,26 @@
-"""Abstract engine surface, unchanged from the reference (umbrella/speculation/base.py:4-59)."""
-from abc import ABC, abstractmethod
+"""The engine contract of the reference (umbrella/speculation/base.py:4-59), enforced at class creation.
+
+Instead of one ``@abstractmethod`` stub per method, ``BaseEngine`` lists the required names and refuses to be
+instantiated by a subclass that leaves any of them out -- the same guarantee ``abc`` gives, with the method set in
+one readable place."""
+
+ENGINE_METHODS = (
+    "initialize",                       # load models, build tables / graphs
+    "prefill", "append",                # text in (tokenised by the engine)
+    "_prefill", "_append",              # token ids in; return False instead of overflowing
+    "build_tree", "verify",             # one speculation iteration = build_tree() then verify()
+    "speculative_decoding",             # (dec_len, seconds, target_steps), streams text to stdout
+    "generate", "generate_stream",      # API entry points (dict in / dict out, generator)
+    "validate_status", "update_generation_args", "reset",
+)
 
 
-class BaseEngine(ABC):
+class BaseEngine:
+    def __new__(cls, *args, **kwargs):
+        missing = [m for m in ENGINE_METHODS if not callable(getattr(cls, m, None))]
+        if missing:
+            raise TypeError(f"Can't instantiate {cls.__name__}: missing engine methods {missing}")
+        return super().__new__(cls)
+
     def __init__(self):
         super().__init__()
-
-    @abstractmethod
-    def initialize(self): ...
-
-    @abstractmethod
-    def verify(self): ...
-
-    @abstractmethod
-    def build_tree(self): ...
-
-    @abstractmethod
-    def prefill(self, text: str): ...
-
-    @abstractmethod
-    def append(self, text: str): ...
-
-    @abstractmethod
-    def _prefill(self, input_ids): ...
-
-    @abstractmethod
-    def _append(self, input_ids): ...
-
-    @abstractmethod
-    def speculative_decoding(self, max_new_tokens: int): ...
-
-    @abstractmethod
-    def validate_status(self): ...
-
-    @abstractmethod
-    def update_generation_args(self, **generation_args): ...
-
-    @abstractmethod
-    def reset(self): ...
-
-    @abstractmethod
-    def generate(self, **api_args): ...
-
-    @abstractmethod
-    def generate_stream(self, **api_args): ...

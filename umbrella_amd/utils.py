@@ -1,7 +1,24 @@
-class TextColors:
-    COLORS = {"black": "\033[30m", "red": "\033[31m", "green": "\033[32m", "yellow": "\033[33m",
-              "blue": "\033[34m", "magenta": "\033[35m", "cyan": "\033[36m", "white": "\033[37m", "reset": "\033[0m"}
+"""Terminal colouring helper with the reference's call shape: ``TextColors.colorize(text, "cyan")``."""
+from enum import Enum
 
-    @staticmethod
-    def colorize(text, color):
-        return f"{TextColors.COLORS.get(color.lower(), TextColors.COLORS['reset'])}{text}{TextColors.COLORS['reset']}"
+
+class _Ansi(Enum):
+    black, red, green, yellow, blue, magenta, cyan, white = range(30, 38)
+
+    @property
+    def code(self) -> str:
+        return f"\x1b[{self.value}m"
+
+
+_RESET = "\x1b[0m"
+
+
+class TextColors:
+    #: name -> escape sequence (kept as a mapping because callers index it)
+    COLORS = {**{c.name: c.code for c in _Ansi}, "reset": _RESET}
+
+    @classmethod
+    def colorize(cls, text, color: str) -> str:
+        """Wrap `text` in the colour's escape codes; unknown colours leave it unstyled."""
+        prefix = cls.COLORS.get(str(color).lower(), _RESET)
+        return "".join((prefix, str(text), _RESET))
