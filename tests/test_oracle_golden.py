@@ -68,6 +68,32 @@ def test_sequoia_generator_kat():
     assert sequoia.generate(5, 6, gm["5x6_acc"]) == gm["5x6"]
 
 
+def test_shipped_growmaps_are_generator_outputs():
+    """umbrella_amd/trees/*.json: each file is what this repository's generator produces for the recorded acceptance
+    vector (scripts/fit_growmaps.py found vectors whose trees have the topology of the growmaps the reference
+    ships under the same names), and satisfies the layout the static engine relies on."""
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree, successor_list_to_mask
+    tdir = os.path.join(os.path.dirname(GOLD), "..", "umbrella_amd", "trees")
+    with open(os.path.join(tdir, "acceptance_vectors.json")) as f:
+        vectors = json.load(f)
+    assert {"sequoia_tree-3x4.json", "sequoia_tree-5x6.json", "8b_sequoia_tree-5x6.json"} <= set(vectors)
+    for name, acc in vectors.items():
+        with open(os.path.join(tdir, name)) as f:
+            gm = json.load(f)
+        w, d = len(gm["roots"][1]), len(gm["roots"]) - 1
+        assert gm == generate_sequoia_tree(w, d, acc=acc), name
+        assert gm["size"] == w * d + 1 and gm["mask"] == successor_list_to_mask(gm["Successors"])
+        for lvl, ids in enumerate(gm["roots"]):
+            assert ids == list(range(ids[0], ids[0] + len(ids)))
+            kids = [c for v in ids for c in gm["Successors"][v]]
+            if lvl + 1 < len(gm["roots"]):
+                assert kids == gm["roots"][lvl + 1] and [len(gm["Successors"][v]) for v in ids] == gm["branches"][lvl]
+    with open(os.path.join(GOLD, "growmaps.json")) as f:
+        ref34 = json.load(f)["3x4"]
+    with open(os.path.join(tdir, "sequoia_tree-3x4.json")) as f:
+        assert json.load(f) == ref34                      # same tree as the reference's shipped 3x4
+
+
 def test_model_logits_match_reference():
     ml = np.load(os.path.join(GOLD, "model_logits.npz"))
     m = oracle_model(G["target_cfg"], G["seeds"]["target"], 128)
