@@ -94,6 +94,44 @@ def test_shipped_growmaps_are_generator_outputs():
         assert json.load(f) == ref34                      # same tree as the reference's shipped 3x4
 
 
+def test_reference_config_growmap_paths_resolve():
+    """A reference config's ``growmap_path`` (relative to the reference's examples directory) resolves to the shipped
+    tree of the same name; unknown names fail loudly."""
+    from umbrella_amd.speculation.static_speculation_engine import resolve_growmap_path
+    for name in ("sequoia_tree-3x4.json", "sequoia_tree-5x6.json", "8b_sequoia_tree-6x7.json"):
+        p = resolve_growmap_path("../umbrella/trees/" + name)
+        assert os.path.basename(p) == name and os.path.exists(p)
+    with pytest.raises(FileNotFoundError):
+        resolve_growmap_path("../umbrella/trees/no_such_tree.json")
+
+
+def test_reference_configs_are_consumable():
+    """Every config file the reference ships (fixtures: tests/golden/ref_configs, data only) is accepted by AutoEngine
+    unchanged: engine kind, registry names (the small code drafters need a local directory), growmap path, tree
+    limits.  Construction only -- initialize() needs the GPU."""
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.speculation.auto_engine import AutoEngine
+    from umbrella_amd.speculation.static_speculation_engine import resolve_growmap_path
+    cdir = os.path.join(GOLD, "ref_configs")
+    names = sorted(os.listdir(cdir))
+    assert len(names) == 11
+    local_only = {"InfiniAILab/CodeDrafter-500M"}
+    for name in names:
+        with open(os.path.join(cdir, name)) as f:
+            cfg = json.load(f)
+        for k in ("generation_length", "max_turns", "template"):      # consumed by the example scripts
+            cfg.pop(k, None)
+        eng = AutoEngine.from_config("cuda:0", **dict(cfg))
+        assert type(eng).__name__ == ("StaticSpeculationEngine" if cfg["engine"] == "static" else "DynamicSpeculationEngine")
+        for key in ("model", "draft_model"):
+            assert cfg[key] in KNOWN or cfg[key] in local_only, (name, cfg[key])
+        if cfg["engine"] == "static":
+            assert os.path.exists(resolve_growmap_path(cfg["growmap_path"]))
+        else:
+            assert cfg["width"] * cfg["num_beams"] <= 1024 and cfg["width"] <= 64
+            assert cfg["width"] * cfg["depth"] + 1 <= 1024             # accept scan limit
+
+
 def test_model_logits_match_reference():
     ml = np.load(os.path.join(GOLD, "model_logits.npz"))
     m = oracle_model(G["target_cfg"], G["seeds"]["target"], 128)

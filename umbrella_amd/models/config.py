@@ -134,6 +134,30 @@ KNOWN["solidrust/Mistral-7B-Instruct-v0.3-AWQ"] = _mistral(32768, 4096, 14336, 3
 # head_dim 128 with hidden 5120: attention width Hq*D = 4096 != hidden (mistral.py:28,101)
 KNOWN["mistralai/Mistral-Small-24B-Instruct-2501"] = _mistral(131072, 5120, 32768, 40, 100000000.0, name="mistral-small-24b")
 KNOWN["stelterlab/Mistral-Small-24B-Instruct-2501-AWQ"] = _mistral(131072, 5120, 32768, 40, 100000000.0, awq=True, name="mistral-small-24b-awq")
+# further Llama-family ids of the reference registry (auto_model.py:9-20,58-79) with public dims
+_L70 = dict(hidden_size=8192, intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8,
+            head_dim=128)
+_L8 = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+           head_dim=128)
+for _name in ("ibnzterrell/Meta-Llama-3.3-70B-Instruct-AWQ-INT4", "lambdalabs/Llama-3.3-70B-Instruct-AWQ-4bit",
+              "casperhansen/deepseek-r1-distill-llama-70b-awq"):
+    KNOWN[_name] = _l(**_L70, rope_scaling=LLAMA31_ROPE, awq=True, name="llama-70b-awq")
+for _name in ("meta-llama/Llama-3.3-70B-Instruct", "meta-llama/Llama-3.1-70B-Instruct"):
+    KNOWN[_name] = _l(**_L70, rope_scaling=LLAMA31_ROPE, name="llama-3.x-70b")
+# Llama 3 (8k context, no rope scaling, eos = <|end_of_text|>, <|eot_id|>)
+KNOWN["meta-llama/Meta-Llama-3-70B-Instruct"] = _l(**_L70, max_position_embeddings=8192, eos_token_id=[128001, 128009],
+                                                    name="llama-3-70b")
+KNOWN["meta-llama/Meta-Llama-3-8B-Instruct"] = _l(**_L8, max_position_embeddings=8192, eos_token_id=[128001, 128009],
+                                                   name="llama-3-8b")
+KNOWN["meta-llama/Llama-3.2-3B-Instruct"] = _l(hidden_size=3072, intermediate_size=8192, num_hidden_layers=28,
+    num_attention_heads=24, num_key_value_heads=8, head_dim=128, rope_scaling=LLAMA3_ROPE, tie_word_embeddings=True,
+    name="llama-3.2-3b")
+KNOWN["facebook/layerskip-llama3.2-1B"] = KNOWN["meta-llama/Llama-3.2-1B-Instruct"]
+KNOWN["Felladrin/Llama-68M-Chat-v1"] = _l(vocab_size=32000, hidden_size=768, intermediate_size=3072, num_hidden_layers=2,
+    num_attention_heads=12, num_key_value_heads=12, head_dim=64, rms_norm_eps=1e-6, rope_theta=10000.0,
+    max_position_embeddings=2048, eos_token_id=[2], name="llama-68m")
+# The reference's small code drafters (Zhuominc/*, InfiniAILab/CodeDrafter-500M) publish no dims here: pass a local
+# directory with config.json for those.
 KNOWN["meta-llama/Llama-3.2-1B"] = KNOWN["meta-llama/Llama-3.2-1B-Instruct"]
 KNOWN["meta-llama/Meta-Llama-3.1-8B-Instruct"] = KNOWN["meta-llama/Llama-3.1-8B-Instruct"]
 

@@ -10,6 +10,7 @@ and KV compaction of one iteration replay as a single hipGraph.
 from __future__ import annotations
 
 import json
+import os
 
 import torch
 
@@ -17,6 +18,17 @@ from .. import _lib
 from ..models.llama import pack_mask_bits
 from .engine_common import HipEngine, logger
 from ..utils import TextColors
+
+
+def resolve_growmap_path(path: str) -> str:
+    """Reference configs point at ``../umbrella/trees/<name>.json`` relative to its examples directory; when that
+    path does not exist here, the tree of the same file name shipped in ``umbrella_amd/trees`` is used."""
+    if os.path.exists(path):
+        return path
+    shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "trees", os.path.basename(path))
+    if os.path.exists(shipped):
+        return shipped
+    raise FileNotFoundError(f"growmap '{path}' not found (also looked for {shipped})")
 
 
 class StaticSpeculationEngine(HipEngine):
@@ -35,7 +47,7 @@ class StaticSpeculationEngine(HipEngine):
 
     def initialize(self):
         if self.growmap is None:
-            with open(self.growmap_path, "r") as f:
+            with open(resolve_growmap_path(self.growmap_path), "r") as f:
                 self.growmap = json.load(f)
         gm, dev = self.growmap, self.device
         T = gm["size"]
