@@ -301,6 +301,27 @@ def test_generation_stops_at_context_limit(dev):
     assert eng.generate(input_ids=[], max_new_tokens=8)["generated_tokens"] == []
 
 
+def test_generate_stream_matches_generate(dev):
+    """generate_stream (static:437-566): the streamed text grows monotonically, its final state is the text of the
+    tokens generate() returns (minus the pending bonus token), the perf line is well formed, the engine is reset
+    afterwards, and an oversized prompt yields the reference's overflow message."""
+    from hip_helpers import static_engine
+    dtype = torch.float16
+    eng, _ = static_engine(G, dev, dtype, self_draft=True)
+    ref = eng.generate(input_ids=PROMPT, max_new_tokens=24)["generated_tokens"]
+    chunks = list(eng.generate_stream(input_ids=PROMPT, max_new_tokens=24))
+    assert len(chunks) >= 2 and all(isinstance(t, str) and isinstance(p, str) for t, p in chunks)
+    texts = [t for t, _ in chunks]
+    assert all(b.startswith(a.rstrip()) or b.startswith(a) for a, b in zip(texts, texts[1:]))
+    streamed = [int(w) for w in texts[-1].split()]
+    assert streamed == ref[:len(streamed)] and len(ref) - len(streamed) <= 1
+    assert chunks[-1][1].startswith("Output Tokens ") and "Avg Accept Tokens" in chunks[-1][1]
+    assert eng.num_nodes == 0                                              # reset after the stream ends
+    over = list(eng.generate_stream(input_ids=list(range(6, 6 + 250)), max_new_tokens=8))
+    assert over == [("Exceeding reserved allowed context length",) * 2]
+    assert list(eng.generate_stream(input_ids=[], max_new_tokens=8)) == []
+
+
 def test_measure_acceptance_rate(dev):
     """Sequoia tooling (examples/construct_sequoia.py of the reference): a model drafting for itself is accepted
     at rank 0 everywhere; an unrelated draft's counts equal the oracle's rank statistics within near-tie slack."""
