@@ -225,7 +225,8 @@ def main():
     # continuation is re-recorded under the knob's own execution pattern until it is a fixed point
     # (each pass reproduces the previous one bit-for-bit up to its first divergence).
     passes = 0
-    for passes in range(1, 9):
+    max_passes = max(8, min(40, (args.warmup + args.steps + 15) // 16))   # ~1 near-tie flip per 50 tokens: long runs need more
+    for passes in range(1, max_passes + 1):
         eng.reset()
         assert eng._prefill(prompt)
         eng.set_oracle_draft(truth, start, acc, seed=args.seed)
