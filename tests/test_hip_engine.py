@@ -322,6 +322,21 @@ def test_generate_stream_matches_generate(dev):
     assert list(eng.generate_stream(input_ids=[], max_new_tokens=8)) == []
 
 
+def test_long_context_spans_and_wide_prefill(dev):
+    """A 2150-token prompt on a 4096-slot engine: prefill runs in 256-token chunks through the T > 64 kernels, the
+    tree attention crosses into its second 2048-key span (last-arriver merge) during decoding, and the generated
+    tokens are still the fp32 oracle target's greedy choices."""
+    from hip_helpers import check_greedy, static_engine
+    dtype = torch.float16
+    eng, sd = static_engine(G, dev, dtype, self_draft=True, max_length=4096, safe_buffer=16)
+    g = torch.Generator().manual_seed(9)
+    prompt = torch.randint(6, 500, (2150,), generator=g).tolist()
+    out = eng.generate(input_ids=prompt, max_new_tokens=20)
+    assert len(out["generated_tokens"]) >= 20
+    check_greedy(G, sd, prompt, out["generated_tokens"], dtype, tol=0.09)
+    assert out["avg_accept_tokens"] > 2.0
+
+
 def test_measure_acceptance_rate(dev):
     """Sequoia tooling (examples/construct_sequoia.py of the reference): a model drafting for itself is accepted
     at rank 0 everywhere; an unrelated draft's counts equal the oracle's rank statistics within near-tie slack."""
