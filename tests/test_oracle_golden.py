@@ -106,21 +106,18 @@ def test_reference_config_growmap_paths_resolve():
 
 
 def test_reference_configs_are_consumable():
-    """Every config file the reference ships (fixtures: tests/golden/ref_configs, data only) is accepted by AutoEngine
-    unchanged: engine kind, registry names (the small code drafters need a local directory), growmap path, tree
-    limits.  Construction only -- initialize() needs the GPU."""
+    """Every config the reference ships (engine keys recorded in tests/golden/ref_config_facts.json by
+    make_ref_config_facts.py) is accepted by AutoEngine unchanged: engine kind, registry names (the small code
+    drafters need a local directory), growmap path, tree limits.  Construction only -- initialize() needs the GPU."""
     from umbrella_amd.models.config import KNOWN
     from umbrella_amd.speculation.auto_engine import AutoEngine
     from umbrella_amd.speculation.static_speculation_engine import resolve_growmap_path
-    cdir = os.path.join(GOLD, "ref_configs")
-    names = sorted(os.listdir(cdir))
-    assert len(names) == 11
+    with open(os.path.join(GOLD, "ref_config_facts.json")) as f:
+        facts = json.load(f)
+    assert len(facts) == 11
     local_only = {"InfiniAILab/CodeDrafter-500M"}
-    for name in names:
-        with open(os.path.join(cdir, name)) as f:
-            cfg = json.load(f)
-        for k in ("generation_length", "max_turns", "template"):      # consumed by the example scripts
-            cfg.pop(k, None)
+    for name, rec in facts.items():
+        cfg = rec["engine_kwargs"]
         eng = AutoEngine.from_config("cuda:0", **dict(cfg))
         assert type(eng).__name__ == ("StaticSpeculationEngine" if cfg["engine"] == "static" else "DynamicSpeculationEngine")
         for key in ("model", "draft_model"):
