@@ -63,7 +63,7 @@ def main():
         gm = generate_sequoia_tree(width, depth, acc=vectors[name])      # from the rounded, recorded vector
         assert gm["Successors"] == target["Successors"], name
         with open(os.path.join(OUT, name), "w") as f:
-            json.dump(gm, f, indent=4)
+            json.dump(gm, f, separators=(",", ":"), sort_keys=True)      # compact: these are generated artefacts
         print(name, "width", width, "depth", depth, "acc", vectors[name])
     with open(os.path.join(OUT, "acceptance_vectors.json"), "w") as f:
         json.dump(vectors, f, indent=1)
