@@ -4,7 +4,7 @@ Avg Accept Tokens = sum(tokens) / sum(target steps), TPOT = sum(time) / sum(toke
 MT-Bench is not available offline: prompts are synthetic token ids with the MT-Bench length profile
 (first turn 64..512 tokens incl. system prompt, second turn 32 tokens).
 
-    python examples/spec_bench.py --configuration configs/greedy_config_mi355x_70b.json --num-prompts 8
+    python examples/spec_bench.py --configuration configs/static_70b_awq_on_device.yaml --num-prompts 8
 """
 import argparse
 import contextlib
@@ -17,14 +17,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from umbrella_amd.speculation.auto_engine import AutoEngine  # noqa: E402
+from umbrella_amd.utils import load_config  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--configuration", default="configs/code_config_mi355x_8b.json")
+ap.add_argument("--configuration", default="configs/static_8b_code.yaml")
 ap.add_argument("--num-prompts", type=int, default=8)
 ap.add_argument("--verbose", action="store_true", help="stream the decoded ids like the reference does")
 args = ap.parse_args()
-with open(args.configuration) as f:
-    config = json.load(f)
+config = load_config(args.configuration)
 GEN_LEN = config.pop("generation_length", 256)
 MAX_TURNS = config.pop("max_turns", 2)
 config.pop("template", None)

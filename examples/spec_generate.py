@@ -1,7 +1,7 @@
 """Two-turn speculative-decoding demo on token ids (counterpart of the reference's
 examples/spec_generate.py:26-57: prefill -> decode -> append -> decode -> reset).
 
-    python examples/spec_generate.py --configuration configs/greedy_config_mi355x_70b.json
+    python examples/spec_generate.py --configuration configs/static_70b_awq_on_device.yaml
 """
 import argparse
 import json
@@ -12,13 +12,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from umbrella_amd.speculation.auto_engine import AutoEngine  # noqa: E402
+from umbrella_amd.utils import load_config  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--configuration", default="configs/code_config_mi355x_8b.json")
+ap.add_argument("--configuration", default="configs/static_8b_code.yaml")
 ap.add_argument("--prompt-len", type=int, default=128)
 args = ap.parse_args()
-with open(args.configuration) as f:
-    config = json.load(f)
+config = load_config(args.configuration)
 GEN_LEN = config.pop("generation_length", 256)
 config.pop("max_turns", None), config.pop("template", None)
 dtype = torch.float16 if "awq" in config["model"].lower() else torch.bfloat16

@@ -129,6 +129,20 @@ def test_reference_configs_are_consumable():
             assert cfg["width"] * cfg["depth"] + 1 <= 1024             # accept scan limit
 
 
+def test_shipped_configs_load():
+    """configs/*.yaml parse into engine kwargs AutoEngine accepts (construction only)."""
+    from umbrella_amd.speculation.auto_engine import AutoEngine
+    from umbrella_amd.utils import load_config
+    cdir = os.path.join(os.path.dirname(GOLD), "..", "configs")
+    names = sorted(n for n in os.listdir(cdir) if n.endswith(".yaml"))
+    assert len(names) >= 3
+    for n in names:
+        cfg = load_config(os.path.join(cdir, n))
+        for k in ("generation_length", "max_turns", "template"):
+            cfg.pop(k, None)
+        assert AutoEngine.from_config("cuda:0", **cfg) is not None
+
+
 def test_model_logits_match_reference():
     ml = np.load(os.path.join(GOLD, "model_logits.npz"))
     m = oracle_model(G["target_cfg"], G["seeds"]["target"], 128)

@@ -22,3 +22,13 @@ class TextColors:
         """Wrap `text` in the colour's escape codes; unknown colours leave it unstyled."""
         prefix = cls.COLORS.get(str(color).lower(), _RESET)
         return "".join((prefix, str(text), _RESET))
+
+
+def load_config(path: str) -> dict:
+    """Engine configuration file -> kwargs dict.  ``.json`` (the reference's format) or ``.yaml`` / ``.yml``."""
+    import json
+    with open(path) as f:
+        if path.endswith((".yaml", ".yml")):
+            import yaml
+            return dict(yaml.safe_load(f))
+        return json.load(f)
