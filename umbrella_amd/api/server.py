@@ -26,30 +26,37 @@ class APIServer:
         self.server_socket = None
 
     # -- per-client reader -------------------------------------------------------------------------------
+    def _requests(self, conn, addr):
+        """Frames from one client until it says terminate, hangs up, or the server is closing."""
+        while not self._closing.is_set():
+            try:
+                frame = receive_data(conn)
+            except Exception as err:              # closed socket / bad frame: drop this client only
+                _log.error(TextColors.colorize(f"client {addr}: {err}", "red"))
+                return
+            if frame.get("terminate", False):
+                return
+            yield frame
+
     def handle_client(self, conn, addr):
         _log.info(TextColors.colorize(f"client {addr} connected", "cyan"))
         with conn:
             send_data(conn, _GREETING)
-            while not self._closing.is_set():
-                try:
-                    request = receive_data(conn)
-                except Exception as err:          # closed socket / bad frame: drop this client only
-                    _log.error(TextColors.colorize(f"client {addr}: {err}", "red"))
-                    break
-                if request.get("terminate", False):
-                    break
+            for request in self._requests(conn, addr):
                 self.message_queue.put((addr, conn, request))
         _log.info(TextColors.colorize(f"client {addr} disconnected", "cyan"))
 
     # -- the only thread that touches the engine ------------------------------------------------------------
+    def _answer(self, request: dict) -> dict:
+        with self.queue_lock:
+            result = self.engine.generate(**request)
+        return dict(result, processed=True, response="Processed successfully")
+
     def process_queue(self):
-        while True:
-            addr, conn, request = self.message_queue.get()
-            with self.queue_lock:
-                answer = dict(self.engine.generate(**request), processed=True, response="Processed successfully")
+        for addr, conn, request in iter(self.message_queue.get, None):
             try:
-                send_data(conn, answer)
-            except Exception as err:
+                send_data(conn, self._answer(request))
+            except OSError as err:
                 _log.error(TextColors.colorize(f"reply to {addr} failed: {err}", "red"))
 
     def _ensure_engine(self):
