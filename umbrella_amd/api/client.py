@@ -25,24 +25,28 @@ def _dial(host: str, port: int, pause: float) -> socket.socket:
 
 
 class APIClient:
-    def __init__(self, port: int, host: str = "127.0.0.1", retry_seconds: float = 5.0):
+    def __init__(self, port: int, host: str = "127.0.0.1", retry_seconds: float = 5.0, wire: str = "json"):
         self.host, self.port, self.retry_seconds = host, port, retry_seconds
+        self.wire = wire                          # "pickle" to talk to an unmodified reference server (trusted host only)
         self.client_socket = None
 
     def run(self):
         self.client_socket = _dial(self.host, self.port, self.retry_seconds)
-        greeting = api_utils.receive_data(self.client_socket)      # the server greets every new connection
+        greeting = self._recv()                   # the server greets every new connection
         _log.info(TextColors.colorize(f"connected: {greeting}", "cyan"))
         return greeting
 
+    def _recv(self):
+        return api_utils.receive_data(self.client_socket, allow_pickle=self.wire == "pickle")
+
     def get_output(self, **api_args):
-        api_utils.send_data(self.client_socket, api_args)
-        return api_utils.receive_data(self.client_socket)
+        api_utils.send_data(self.client_socket, api_args, self.wire)
+        return self._recv()
 
     def close(self):
         sock, self.client_socket = self.client_socket, None
         if sock is not None:
-            api_utils.send_data(sock, {"terminate": True})
+            api_utils.send_data(sock, {"terminate": True}, self.wire)
             sock.close()
 
     __enter__ = lambda self: (self.run(), self)[1]                  # noqa: E731

@@ -16,10 +16,11 @@ _GREETING = {"status": "connected", "message": "Welcome to the server!"}
 
 class APIServer:
     def __init__(self, config, device: str = "cuda:0", port: int = 65432, max_client: int = 4, host: str = "127.0.0.1",
-                 engine=None):
+                 engine=None, wire: str = "json"):
         self.config, self.device = config, device
         self.host, self.port, self.max_client = host, port, max_client
         self.engine = engine                      # a ready engine may be injected (tests)
+        self.wire = wire                          # "pickle": serve unmodified reference clients (trusted host only)
         self.message_queue: queue.Queue = queue.Queue()
         self.queue_lock = threading.Lock()
         self._closing = threading.Event()
@@ -30,7 +31,7 @@ class APIServer:
         """Frames from one client until it says terminate, hangs up, or the server is closing."""
         while not self._closing.is_set():
             try:
-                frame = receive_data(conn)
+                frame = receive_data(conn, allow_pickle=self.wire == "pickle")
             except Exception as err:              # closed socket / bad frame: drop this client only
                 _log.error(TextColors.colorize(f"client {addr}: {err}", "red"))
                 return
@@ -41,7 +42,7 @@ class APIServer:
     def handle_client(self, conn, addr):
         _log.info(TextColors.colorize(f"client {addr} connected", "cyan"))
         with conn:
-            send_data(conn, _GREETING)
+            send_data(conn, _GREETING, self.wire)
             for request in self._requests(conn, addr):
                 self.message_queue.put((addr, conn, request))
         _log.info(TextColors.colorize(f"client {addr} disconnected", "cyan"))
@@ -55,7 +56,7 @@ class APIServer:
     def process_queue(self):
         for addr, conn, request in iter(self.message_queue.get, None):
             try:
-                send_data(conn, self._answer(request))
+                send_data(conn, self._answer(request), self.wire)
             except OSError as err:
                 _log.error(TextColors.colorize(f"reply to {addr} failed: {err}", "red"))
 
