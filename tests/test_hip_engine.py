@@ -514,3 +514,82 @@ def test_full_size_1b_shapes_greedy_property(dev):
     for i, tok in enumerate(toks):
         row = logits[len(prompt) + i - 1]
         assert float(row.max() - row[tok]) <= 0.06, (i, tok, float(row.max() - row[tok]))
+
+
+def _awq_dequant_torch(qweight, qzeros, scales, group=128):
+    """AutoAWQ GEMM format -> W [K, N] (scales dtype), torch on any device (same maths as oracle.ops.awq_dequant)."""
+    from oracle.ops import AWQ_ORDER
+    def unpack(p):
+        out = torch.empty(p.shape[0], p.shape[1], 8, dtype=torch.int32, device=p.device)
+        for i, col in enumerate(AWQ_ORDER):
+            out[:, :, col] = (p >> (4 * i)) & 0xF
+        return out.reshape(p.shape[0], p.shape[1] * 8)
+    q, z = unpack(qweight).float(), unpack(qzeros).float().repeat_interleave(group, dim=0)
+    return ((q - z) * scales.float().repeat_interleave(group, dim=0)).to(scales.dtype)
+
+
+def test_full_width_70b_awq_layers_vs_fp32(dev):
+    """BASELINE headline shapes at full width (Llama-3.1-70B-AWQ dims: H 8192, I 28672, 64/8 heads, D 128, V 128256,
+    group 128), two layers deep: the HIP runtime on a 64-token causal prefix + a 13-node Sequoia tree against an fp32
+    restatement built from the oracle's ops on the same AutoAWQ tensors (dequantise-then-matmul, awq_utils.py:63-86)."""
+    import copy
+    import torch.nn.functional as F
+    from oracle import ops as O
+    from hip_helpers import growmap
+    from umbrella_amd.models.config import KNOWN, rope_inv_freq
+    from umbrella_amd.models.llama import Llama
+    from umbrella_amd.models.synthetic import linear_shapes, synth_awq_tensors
+    name, dtype = "hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", torch.float16
+    cfg = copy.copy(KNOWN[name])
+    cfg.num_hidden_layers = 2
+    gen = torch.Generator(device=dev).manual_seed(3)
+    H, V = cfg.hidden_size, cfg.vocab_size
+    sd = {"model.embed_tokens.weight": (torch.randn(V, H, device=dev, generator=gen) * 0.05).to(dtype),
+          "lm_head.weight": (torch.randn(V, H, device=dev, generator=gen) * 0.02).to(dtype),
+          "model.norm.weight": (1 + 0.1 * torch.randn(H, device=dev, generator=gen)).to(dtype)}
+    for i in range(2):
+        p = f"model.layers.{i}."
+        for ln, (n, k) in linear_shapes(cfg).items():
+            qw, qz, sc = synth_awq_tensors(n, k, 128, dev, gen, 0.02)
+            sd[p + ln + ".qweight"], sd[p + ln + ".qzeros"], sd[p + ln + ".scales"] = qw, qz, sc
+        for nm in ("input_layernorm", "post_attention_layernorm"):
+            sd[p + nm + ".weight"] = (1 + 0.1 * torch.randn(H, device=dev, generator=gen)).to(dtype)
+    m = Llama(name, max_length=256, device=str(dev), dtype=dtype, state_dict=sd, config=cfg)
+    m.alloc()
+    m.reserve(96)
+    gm = growmap("3x4")
+    P, T = 64, gm["size"]
+    n = P + T
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(3, 128000, (1, n), generator=g)
+    pos = torch.cat([torch.arange(P), P + torch.tensor(gm["depth"])])
+    mask = torch.zeros(n, n, dtype=torch.bool)
+    mask[:P, :P] = torch.tril(torch.ones(P, P, dtype=torch.bool))
+    mask[P:, :P] = True
+    mask[P:, P:] = torch.tensor(gm["mask"]) == 1
+    got = m.inference(ids, pos[None], mask, torch.arange(n))[0]
+    # ---- fp32 reference on the device, weights dequantised exactly as AwqLinear's fallback branch does
+    inv, scl = rope_inv_freq(cfg)
+    cos, sin = (t.to(dev) for t in O.rope_cache(inv, scl, 256, dtype))
+    lin = lambda x, base: x @ _awq_dequant_torch(sd[base + ".qweight"], sd[base + ".qzeros"], sd[base + ".scales"]).float()
+    h = F.embedding(ids[0].to(dev), sd["model.embed_tokens.weight"]).float()
+    md, pd = mask.to(dev), pos.to(dev)
+    for i in range(2):
+        p = f"model.layers.{i}."
+        x = O.rmsnorm(h, sd[p + "input_layernorm.weight"].float(), cfg.rms_norm_eps)
+        q = lin(x, p + "self_attn.q_proj").view(n, 64, 128)
+        k = lin(x, p + "self_attn.k_proj").view(n, 8, 128)
+        v = lin(x, p + "self_attn.v_proj").view(n, 8, 128)
+        q, k = O.apply_rope(q, k, cos.float(), sin.float(), pd)
+        a = O.masked_attention(q, k, v, md).reshape(n, 8192)
+        h = h + lin(a, p + "self_attn.o_proj")
+        x = O.rmsnorm(h, sd[p + "post_attention_layernorm.weight"].float(), cfg.rms_norm_eps)
+        h = h + lin(F.silu(lin(x, p + "mlp.gate_proj")) * lin(x, p + "mlp.up_proj"), p + "mlp.down_proj")
+    ref = O.rmsnorm(h, sd["model.norm.weight"].float(), cfg.rms_norm_eps) @ sd["lm_head.weight"].float().t()
+    err = (got - ref).abs()
+    scale = max(1.0, float(ref.abs().max()) / 16.0)
+    assert float(err.max()) <= 0.06 * scale + float(ref.abs().max()) * 2.0 ** -9, (float(err.max()), float(ref.abs().max()))
+    # the tree rows agree on the arg-max wherever the fp32 margin exceeds the 16-bit noise
+    top2 = ref[P:].topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4 * float(err.max())
+    assert torch.equal(got[P:].argmax(-1)[clear], ref[P:].argmax(-1)[clear])
