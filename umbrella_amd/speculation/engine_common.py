@@ -122,7 +122,10 @@ class HipEngine(BaseEngine):
 
     def _feed(self, lo, hi):
         ids = self.tokens[lo:hi]
-        self.draft_model.prefill_tokens(ids, lo, want_logits=False)
+        # with the look-back schedule the token before `lo` may still lack draft KV (a deepest-level node accepted in
+        # the iteration that ended the previous turn): the draft's prefill starts one slot earlier and re-derives it
+        dlo = lo - 1 if (self.lookback and lo > 0) else lo
+        self.draft_model.prefill_tokens(self.tokens[dlo:hi], dlo, want_logits=False)
         row = self.target_model.prefill_tokens(ids, lo, want_logits=True)
         first = self._first_token(row)
         self.tokens[hi:hi + 1] = first
