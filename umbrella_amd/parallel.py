@@ -264,7 +264,8 @@ class PipelinedStaticEngine(_Static):
 
     def _feed(self, lo, hi):
         ids = self.tokens[lo:hi]
-        self.draft_model.prefill_tokens(ids, lo, want_logits=False)
+        dlo = lo - 1 if (self.lookback and lo > 0) else lo          # see HipEngine._feed
+        self.draft_model.prefill_tokens(self.tokens[dlo:hi], dlo, want_logits=False)
         first = self.target_model.prefill_tokens(ids, lo, want_logits=True)
         self.tokens[hi:hi + 1] = first
         self.num_nodes = hi
