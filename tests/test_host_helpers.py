@@ -1,0 +1,76 @@
+"""Host-side helpers of the product (CPU): the reference-surface utilities against the golden vectors recorded from
+the reference, the tokenizer stand-in, mask packing, configuration registry plumbing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLD
+
+OPS = np.load(os.path.join(GOLD, "ops.npz"))
+
+
+def test_logit_helpers_match_reference_vectors():
+    from umbrella_amd.speculation import speculation_utils as su
+    lg, ids = torch.from_numpy(OPS["rp_logits"]), torch.from_numpy(OPS["rp_ids"])
+    assert torch.equal(su.apply_repetition_penalty(ids, lg, 1.05), torch.from_numpy(OPS["rp_out"]))
+    assert torch.equal(su.apply_topk(lg, 8), torch.from_numpy(OPS["topk_out"]))
+    m = su.make_causal_mask((1, 5), "cpu")
+    assert m.dtype == torch.bool and torch.equal(m, torch.tril(torch.ones(5, 5, dtype=torch.bool)))
+    assert su.find_first_element_position(torch.tensor([[7, 3, 9, 5]]), [5, 3]) == 1
+    assert su.find_first_element_position(torch.tensor([7, 9]), [5, 3]) == -1
+
+
+@pytest.mark.parametrize("text,done", [("It works.", True), ("really?  ", True), ("好的。", True), ("wait", False),
+                                       ("a.b", False), ("", False), ("Stop!\n", True)])
+def test_sentence_complete_rule(text, done):
+    from umbrella_amd.speculation.speculation_utils import is_sentence_complete_regex
+    assert is_sentence_complete_regex(text) is done            # speculation_utils.py:356-358
+
+
+def test_id_tokenizer_roundtrip():
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    tok = IdTokenizer()
+    ids = tok.encode("12 7 99", return_tensors="pt")
+    assert ids.tolist() == [[0, 12, 7, 99]]                    # BOS prepended, dropped by append() (static:140)
+    assert tok.decode(ids[0, 1:]) == "12 7 99" and tok.encode("5") == [0, 5]
+
+
+def test_pack_mask_bits_layout():
+    from umbrella_amd.models.llama import pack_mask_bits
+    m = torch.zeros(3, 130, dtype=torch.bool)
+    m[0, 0] = m[1, 63] = m[1, 64] = m[2, 129] = True
+    bits = pack_mask_bits(m)
+    assert bits.shape == (3, 3) and bits.dtype == torch.int64
+    u = lambda x: int(x) & (2 ** 64 - 1)
+    assert u(bits[0, 0]) == 1 and u(bits[1, 0]) == 1 << 63 and u(bits[1, 1]) == 1 and u(bits[2, 2]) == 1 << 1
+    assert int(bits[0, 1]) == 0 and int(bits[2, 0]) == 0
+
+
+def test_model_registry_contract():
+    """AutoModelLM: the three mappings, ValueError for unknown names, cuda_graph wins over offload
+    (auto_model.py:165-182) -- without touching the GPU (construction is lazy until alloc())."""
+    from umbrella_amd.models import AutoModelLM
+    from umbrella_amd.models.config import KNOWN
+    assert set(AutoModelLM._MODEL_MAPPING) == set(KNOWN) == set(AutoModelLM._OFFLOAD_MODEL_MAPPING)
+    with pytest.raises(ValueError):
+        AutoModelLM.from_pretrained("nobody/unknown-model")
+    m = AutoModelLM.from_pretrained("meta-llama/Llama-3.2-1B-Instruct", offload=True, cuda_graph=True, max_length=100)
+    assert m.cuda_graph and not m.offload and m.max_length == 128          # rounded up to whole 32-key tiles
+    q = AutoModelLM.from_pretrained("Qwen/Qwen2.5-0.5B-Instruct", max_length=64)
+    assert q.config.attention_bias and not q.fused
+
+
+def test_linear_plan_is_a_function_of_shape_only():
+    """Split / wave plan of the skinny GEMM depends on (N, K, format) alone -- the basis of batch invariance."""
+    import ctypes as C
+    from umbrella_amd import _lib
+    lib = _lib.load()
+    seen = {}
+    for (N, K, awq) in [(57344, 8192, 1), (10240, 8192, 1), (8192, 28672, 1), (128256, 2048, 0), (3072, 2048, 0)]:
+        for _ in range(2):
+            R, S = C.c_int(0), C.c_int(0)
+            lib.umb_gemm_plan(N, K, awq, 0, C.byref(R), C.byref(S))
+            assert seen.setdefault((N, K, awq), (R.value, S.value)) == (R.value, S.value)
+            assert R.value in (1, 2) and 1 <= S.value <= 16 and (K // 128) // S.value >= (4 if awq else 2)
