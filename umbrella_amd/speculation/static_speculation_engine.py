@@ -99,12 +99,17 @@ class StaticSpeculationEngine(HipEngine):
         self._truth, self._truth_start = list(truth), truth_start
         p = np.asarray(list(acc) + [max(0.0, 1.0 - float(sum(acc)))], dtype=np.float64)
         self._acc_p, self._acc_seed = p / p.sum(), seed
+        # rank drawn for absolute position q (seeded by q alone, so every pass / run sees the same draws); tabulated
+        # once -- the per-iteration host work inside a timed loop is then a few list lookups
+        lo, hi = truth_start, truth_start + len(self._truth) + self.tree_depth + 1
+        self._rank_lo = lo
+        self._rank_tbl = [int(np.random.RandomState((seed * 1000003 + q) % (2**31 - 1)).choice(len(self._acc_p), p=self._acc_p))
+                          for q in range(lo, hi)]
         self.enable_override = True
         self._graph = None
         self.diverged = 0
 
     def _fill_override(self):
-        import numpy as np
         tbl = self.override_host
         tbl.fill_(-1)
         i0 = self.num_nodes - self._truth_start
@@ -116,8 +121,7 @@ class StaticSpeculationEngine(HipEngine):
         for d in range(1, self.tree_depth):
             if i0 + d >= len(self._truth) or i0 < 0:
                 break
-            rs = np.random.RandomState((self._acc_seed * 1000003 + self.num_nodes + d) % (2**31 - 1))
-            r = int(rs.choice(len(self._acc_p), p=self._acc_p))
+            r = self._rank_tbl[self.num_nodes + d - self._rank_lo]
             kids = self._succ[node]
             if r >= len(kids):
                 break
