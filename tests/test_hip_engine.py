@@ -437,6 +437,20 @@ def test_pipelined_engine_single_rank(dev):
         eng.initialize()
         out = eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
         assert out == ref
+        # config-driven entry (what examples/spec_generate_pp.py and bench.py --parallel pp use), 1-rank group
+        from umbrella_amd.parallel import build_pipelined_engine, shutdown_pipeline
+        eng2 = build_pipelined_engine(str(dev), dtype=torch.float16, engine="static",
+                                      model="meta-llama/Llama-3.2-1B-Instruct",
+                                      draft_model="meta-llama/Llama-3.2-1B-Instruct",
+                                      growmap_path="../umbrella/trees/sequoia_tree-3x4.json", max_length=256,
+                                      offload=False, cuda_graph=True, num_cache_layers=0, exit_layer=2,
+                                      tokenizer=IdTokenizer())
+        assert eng2 is not None and eng2.tree_size == 13
+        assert eng2._prefill(torch.tensor([PROMPT]))
+        for _ in range(3):
+            eng2.step()
+        assert eng2.num_nodes >= len(PROMPT) + 3
+        shutdown_pipeline(eng2)
     finally:
         dist.destroy_process_group()
 

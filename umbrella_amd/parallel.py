@@ -187,23 +187,32 @@ def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False):
             n_dev.copy_(res[3:4])
 
 
-def run_pp_bench(args, wl, dtype, device, rank, world):
-    """bench.py --parallel pp: one request, target layers sharded over the ranks (static 3x4, greedy)."""
-    import json
-    import time
+def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **config):
+    """Layer-sharded static engine from a reference-style config (``engine: static``, ``model``, ``draft_model``,
+    ``growmap_path`` | ``growmap``, ``max_length`` ...): every rank of the default process group holds a contiguous
+    slice of the target's layers (`split_layers`); rank 0 also holds the draft and gets the engine back, the other
+    ranks serve forwards inside this call until rank 0 sends OP_STOP (`shutdown_pipeline`) and then return None.
+    Launch with torch.distributed.run, one process per GPU; the process group must already be initialised."""
+    import json as _json
 
-    import __graft_entry__ as ge
-    from .models.config import KNOWN
+    from .models.config import KNOWN, LlamaCfg
     from .models.llama import Llama, pack_mask_bits
-    from .sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
-    from .speculation.static_speculation_engine import StaticSpeculationEngine
-    ge.build()
-    gm = generate_sequoia_tree(3, 4)
-    T, depth_levels = gm["size"], len(gm["roots"])
-    cfg = KNOWN[wl["target"]]
+    from .speculation.static_speculation_engine import resolve_growmap_path
+    assert config.pop("engine", "static") == "static", "layer sharding is implemented for the static engine"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    target, draft = config.pop("model"), config.pop("draft_model")
+    gm = config.pop("growmap", None)
+    if gm is None:
+        with open(resolve_growmap_path(config.pop("growmap_path"))) as f:
+            gm = _json.load(f)
+    else:
+        config.pop("growmap_path", None)
+    max_length = config.get("max_length", 8192)
+    cfg = KNOWN[target] if target in KNOWN else LlamaCfg.from_dir(target)
     lo, hi = split_layers(cfg.num_hidden_layers, world)[rank]
-    stage = Llama(wl["target"], max_length=args.max_length, device=device, dtype=dtype, seed=args.seed)
+    stage = Llama(target, max_length=max_length, device=device, dtype=dtype, seed=seed)
     stage.alloc(layer_range=(lo, hi))
+    T, depth_levels = gm["size"], len(gm["roots"])
     stage.reserve(max(stage.CHUNK, T))
     comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.CHUNK, T), depth_levels)
     if rank != 0:
@@ -214,13 +223,34 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
                       n_eos=len(cfg.eos_token_id), max_path=depth_levels)
         tables["mask_words"] = tables["mask_bits"].shape[1]
         stage_worker(stage, comm, tables)
+        return None
+    for k in ("offload", "cuda_graph", "num_cache_layers"):      # single-GPU placement knobs of the reference
+        config.pop(k, None)
+    eng = PipelinedStaticEngine(draft, target, dtype=dtype, device=device, growmap=gm, seed=seed, hip_graph=False,
+                                stage_model=stage, comm=comm, **config)
+    eng.initialize()
+    return eng
+
+
+def shutdown_pipeline(eng):
+    """Rank 0: release the stage workers blocked in build_pipelined_engine."""
+    eng._comm.command(OP_STOP)
+
+
+def run_pp_bench(args, wl, dtype, device, rank, world):
+    """bench.py --parallel pp: one request, target layers sharded over the ranks (static 3x4, greedy)."""
+    import json
+    import time
+
+    import __graft_entry__ as ge
+    from .sequoia_utils import generate_sequoia_tree
+    ge.build()
+    eng = build_pipelined_engine(device, dtype=dtype, seed=args.seed, model=wl["target"], draft_model=wl["draft"],
+                                 growmap=generate_sequoia_tree(3, 4), max_length=args.max_length, exit_layer=16)
+    if eng is None:
         dist.barrier()
         dist.destroy_process_group()
         return None
-    eng = PipelinedStaticEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=gm,
-                                max_length=args.max_length, exit_layer=16, seed=args.seed, hip_graph=False,
-                                stage_model=stage, comm=comm)
-    eng.initialize()
     g = torch.Generator().manual_seed(1234)
     prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)
     assert eng._prefill(prompt)
@@ -234,7 +264,7 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
     torch.cuda.synchronize()
     dt = time.time() - t0
     tokens = eng.num_nodes - start
-    comm.command(OP_STOP)
+    shutdown_pipeline(eng)
     out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
