@@ -704,11 +704,161 @@ __global__ __launch_bounds__(256) void verify_gemm_kernel(const u32x4* __restric
   }
 }
 
+// ------------------------------------------------------------------ verify GEMM, int4 x fp16, weights never in LDS
+// LDS delivers ~64 B / clock / CU for ds_read_b128 on this part, and the 2 x 2 kernel above moves 0.75 KiB of LDS data
+// per MFMA (fragment reads + dequantised-weight and activation stores): a third of the matrix rate at best, which is
+// what every LDS-sharing variant measured.  Here block = 256 output rows x 128 tokens, 4 waves stacked along the
+// rows: wave w owns 64 rows (4 n-tiles) x all 8 token tiles = 4 x 8 accumulators.  Its int4 tiles go HBM ->
+// registers -> exact fp16 dequant -> MFMA A operand, never through LDS; only the activation fragments are shared
+// (16 ds_read_b128 per 64 MFMAs = 0.31 KiB per MFMA with the stores).  <= 256 registers so two blocks share a CU:
+// one wave's dequant and LDS waits hide behind the other's MFMAs.
+template <typename P>
+__global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __restrict__ wp,
+                                                               const unsigned char* __restrict__ meta,
+                                                               const u16* __restrict__ x, int ldx,
+                                                               float* __restrict__ out, int T, int Tv, int N, int K,
+                                                               int S, int epi, GemmFused fx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* sB = reinterpret_cast<u32x4*>(smem);                        // [2 buf][8 tt][2 s][64]   (64-k steps)
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int nblk = N / 256;
+  const int nchunk = (Tv + 127) / 128;
+  const int nb = blockIdx.x % nblk;
+  const int tc = (blockIdx.x / nblk) % nchunk;
+  const int sp = blockIdx.x / (nblk * nchunk);
+  const int KB = K / 128;
+  const int per = (KB + S - 1) / S;
+  const int ks0 = 2 * sp * per, ks1 = 2 * min(KB, sp * per + per);   // 64-k steps
+  const int t0 = tc * 128;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long tile_base = ((long)(nb * 4 + wv) * KB) * 4;             // tile order [N/64][K/128][4]
+  const unsigned* wbase = reinterpret_cast<const unsigned*>(wp + tile_base * 64 + lane);
+  const unsigned char* mbase = meta + tile_base * 64 + j * 4;
+  uint2 ra[4];                                                       // the two dwords of this 64-k half, per n-tile
+  unsigned rm[4];
+  u32x4 rb[4];
+  auto gload = [&](int ks) {
+    const int kb = ks >> 1, hf = ks & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ra[q] = *reinterpret_cast<const uint2*>(wbase + ((long)kb * 4 + q) * 256 + hf * 2);
+      rm[q] = *reinterpret_cast<const unsigned*>(mbase + ((long)kb * 4 + q) * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = wv * 4 + i, tt = f >> 1, sx = f & 1;
+      const int tok = t0 + tt * 16 + j;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rb[i] = (tok < Tv) ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + ks * 64 + sx * 32 + g * 8) : z;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sB[(buf * 16 + wv * 4 + i) * 64 + lane] = rb[i];
+  };
+
+  if (ks0 < ks1) {
+    gload(ks0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int buf = (ks - ks0) & 1;
+    // dequantise this step's two fragments per n-tile from the staged registers, then refill them
+    u32x4 wf[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned mm = rm[q];
+      const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
+      const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
+      const h2 s2 = {sc, sc};
+      const _Float16 nz = -((_Float16)1024.0f + zf), nz16 = -((_Float16)64.0f + zf);
+      const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
+      const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+      unsigned magic = 0x64006400u;
+      asm volatile("" : "+v"(magic));
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const unsigned w = sx ? ra[q].y : ra[q].x, w8 = w >> 8;
+        const h2 q0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
+        const h2 q1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
+        const h2 q2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
+        const h2 q3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
+        wf[q][sx][0] = __builtin_bit_cast(unsigned, (q0 + nz2) * s2);
+        wf[q][sx][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q1, sixteenth, nz16_2) * s2);
+        wf[q][sx][2] = __builtin_bit_cast(unsigned, (q2 + nz2) * s2);
+        wf[q][sx][3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q3, sixteenth, nz16_2) * s2);
+      }
+    }
+    if (ks + 1 < ks1) gload(ks + 1);
+    // activation fragments: the read for fragment i+1 is in flight while fragment i feeds 4 MFMAs
+    const u32x4* sb = sB + (buf * 16) * 64 + lane;
+    u32x4 bcur = sb[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = i >> 1, sx = i & 1;
+      u32x4 bnext = bcur;
+      if (i + 1 < 16) bnext = sb[(i + 1) * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bcur, acc[q][t]);
+      bcur = bnext;
+    }
+    if (ks + 1 < ks1) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int tok = t0 + t * 16 + j;
+    if (tok >= Tv) continue;
+    float inv = 1.f;
+    if (fx.ssq_in) {
+      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      float a = 0.f;
+      for (int q = 0; q < fx.ssq_groups; q += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q); a += v[0]; a += v[1]; a += v[2]; a += v[3]; }
+      inv = rsqrtf(a / fx.ssq_dim + fx.eps);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = acc[q][t];
+      const int ntile = (nb * 4 + wv) * 4 + q;
+      if (epi == EPI_SILU) {
+        v *= inv;
+        const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
+        const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
+        u16* act = reinterpret_cast<u16*>(out);
+        *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + ntile * 8 + g * 2) = pack2<P>(a0, a1);
+      } else {
+        if (epi == EPI_ROUND) { v *= inv; v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
+        *reinterpret_cast<f32x4*>(out + ((long)sp * T + tok) * N + ntile * 16 + g * 4) = v;
+      }
+    }
+  }
+}
+
 template <typename P, int AWQ>
 static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Tv, int N,
                          int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
-  const size_t smem = (size_t)(2 * 8 * 2 + 2 * 8 * 2) * 64 * 16;     // 64 KiB
   const int nchunk = (Tv + 127) / 128;
+  if constexpr (AWQ == 2) {
+    static const bool plain = getenv("UMB_VGEMM_PLAIN") != nullptr;  // diagnostic: the LDS-shared 128 x 128 kernel
+    if (!plain && N % 256 == 0) {
+      hipLaunchKernelGGL((verify_gemm_r_kernel<P>), dim3((unsigned)((N / 256) * nchunk * S)), dim3(256),
+                         (size_t)2 * 16 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv, N,
+                         K, S, epi, fx);
+      UMB_LAUNCH_CHECK();
+      return UMB_OK;
+    }
+  }
+  const size_t smem = (size_t)(2 * 8 * 2 + 2 * 8 * 2) * 64 * 16;     // 64 KiB
   hipLaunchKernelGGL((verify_gemm_kernel<P, AWQ>), dim3((unsigned)((N / 128) * nchunk * S)), dim3(256), smem, st,
                      (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv, N, K, S, epi, fx);
   UMB_LAUNCH_CHECK();
