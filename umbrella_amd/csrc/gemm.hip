@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void verify_gemm_kernel(const u32x4* __restric
   }
 }
 
-// ------------------------------------------------------------------ verify GEMM, int4 x fp16, weights never in LDS
+// ------------------------------------------------------------------ verify GEMM, weights never in LDS (int4 x fp16, dense 16-bit)
 // LDS delivers ~64 B / clock / CU for ds_read_b128 on this part, and the 2 x 2 kernel above moves 0.75 KiB of LDS data
 // per MFMA (fragment reads + dequantised-weight and activation stores): a third of the matrix rate at best, which is
 // what every LDS-sharing variant measured.  Here block = 256 output rows x 128 tokens, 4 waves stacked along the
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void verify_gemm_kernel(const u32x4* __restric
 // registers -> exact fp16 dequant -> MFMA A operand, never through LDS; only the activation fragments are shared
 // (16 ds_read_b128 per 64 MFMAs = 0.31 KiB per MFMA with the stores).  <= 256 registers so two blocks share a CU:
 // one wave's dequant and LDS waits hide behind the other's MFMAs.
-template <typename P>
+template <typename P, int AWQ>
 __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __restrict__ wp,
                                                                const unsigned char* __restrict__ meta,
                                                                const u16* __restrict__ x, int ldx,
@@ -739,18 +739,26 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long tile_base = ((long)(nb * 4 + wv) * KB) * 4;             // tile order [N/64][K/128][4]
+  const long tile_base = ((long)(nb * 4 + wv) * KB) * 4;             // int4 tile order [N/64][K/128][4]
   const unsigned* wbase = reinterpret_cast<const unsigned*>(wp + tile_base * 64 + lane);
-  const unsigned char* mbase = meta + tile_base * 64 + j * 4;
-  uint2 ra[4];                                                       // the two dwords of this 64-k half, per n-tile
+  const unsigned char* mbase = AWQ ? meta + tile_base * 64 + j * 4 : nullptr;
+  const u32x4* dbase = wp + ((long)(nb * 4 + wv) * 4 * KB) * 256 + lane;      // dense tile order [N/16][K/32]
+  uint2 ra[4];                                                       // int4: the two dwords of this 64-k half, per n-tile
   unsigned rm[4];
+  u32x4 rd[AWQ ? 1 : 4][2];                                          // dense: the two 16 x 32 tiles of this step, per n-tile
   u32x4 rb[4];
   auto gload = [&](int ks) {
     const int kb = ks >> 1, hf = ks & 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ra[q] = *reinterpret_cast<const uint2*>(wbase + ((long)kb * 4 + q) * 256 + hf * 2);
-      rm[q] = *reinterpret_cast<const unsigned*>(mbase + ((long)kb * 4 + q) * 64);
+      if (AWQ) {
+        ra[q] = *reinterpret_cast<const uint2*>(wbase + ((long)kb * 4 + q) * 256 + hf * 2);
+        rm[q] = *reinterpret_cast<const unsigned*>(mbase + ((long)kb * 4 + q) * 64);
+      } else {
+        const u32x4* tile = dbase + ((long)q * KB) * 256 + (long)ks * 128;
+        rd[AWQ ? 0 : q][0] = __builtin_nontemporal_load(tile);
+        rd[AWQ ? 0 : q][1] = __builtin_nontemporal_load(tile + 64);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -776,6 +784,7 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
     u32x4 wf[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (!AWQ) { wf[q][0] = rd[AWQ ? 0 : q][0]; wf[q][1] = rd[AWQ ? 0 : q][1]; continue; }
       const unsigned mm = rm[q];
       const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
       const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
@@ -848,10 +857,11 @@ template <typename P, int AWQ>
 static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Tv, int N,
                          int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
   const int nchunk = (Tv + 127) / 128;
-  if constexpr (AWQ == 2) {
+  if constexpr (AWQ != 1) {
     static const bool plain = getenv("UMB_VGEMM_PLAIN") != nullptr;  // diagnostic: the LDS-shared 128 x 128 kernel
-    if (!plain && N % 256 == 0) {
-      hipLaunchKernelGGL((verify_gemm_r_kernel<P>), dim3((unsigned)((N / 256) * nchunk * S)), dim3(256),
+    // 256-row blocks: only when they still give every CU a block (small layers keep the 128-row kernel's finer grid)
+    if (!plain && N % 256 == 0 && (N / 256) * nchunk * S >= 256) {
+      hipLaunchKernelGGL((verify_gemm_r_kernel<P, AWQ>), dim3((unsigned)((N / 256) * nchunk * S)), dim3(256),
                          (size_t)2 * 16 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv, N,
                          K, S, epi, fx);
       UMB_LAUNCH_CHECK();
