@@ -525,3 +525,37 @@ def test_gemm_awq_full_size_properties(dev, N, K):
                            sc[:, c0:c0 + 64].cpu(), 128)
         got = y[:, c0:c0 + 64].cpu()
         assert _rel(got, ref) < 2e-3, (c0, _rel(got, ref))
+
+
+@pytest.mark.parametrize("awq", [True, False])
+@pytest.mark.parametrize("T", [128, 256, 257, 300, 385, 769])
+def test_verify_gemm_wide_full_width(dev, awq, T):
+    """Wide-token GEMMs at 70B widths (N = 8192 / 28672-row groups, so the 256-row register-resident kernels are
+    selected: 128-token blocks, 144-token blocks for T = w d + 1, skinny tail otherwise): every row must equal what
+    the T <= 16 kernel gives for that token alone up to fp32 summation order, and the fp32 reference on slices."""
+    from umbrella_amd.models.llama import PackedLinear
+    from umbrella_amd.models.synthetic import synth_awq_tensors
+    gen = torch.Generator(device=dev).manual_seed(T + awq)
+    N, K = 8192, 2048
+    if awq:
+        qw, qz, sc = synth_awq_tensors(N, K, 128, dev, gen)
+        lin = PackedLinear.from_awq(qw, qz, sc)
+        dtype = torch.float16
+    else:
+        w = (torch.randn(N, K, device=dev, generator=gen) * 0.02).bfloat16()
+        lin = PackedLinear.from_dense(w)
+        dtype = torch.bfloat16
+    x = (torch.randn(T, K, device=dev, generator=gen) * 0.5).to(dtype)
+    y = lin.apply(x)                                                  # wide path
+    rows = [0, 1, 15, 127, 128, T - 2, T - 1]
+    rows = sorted(set(r for r in rows if 0 <= r < T))
+    y1 = torch.cat([lin.apply(x[r:r + 1].contiguous()) for r in rows])
+    scale = float(y1.abs().max())
+    assert float((y[rows] - y1).abs().max()) <= 2e-5 * scale + 1e-6, float((y[rows] - y1).abs().max())
+    if awq:
+        from test_hip_engine import _awq_dequant_torch
+        wd = _awq_dequant_torch(qw[:, :16], qz[:, :16], sc[:, :128]).float()       # first 128 output columns
+    else:
+        wd = w[:128].float().t()
+    ref = x.float() @ wd
+    assert float((y[:, :128] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())

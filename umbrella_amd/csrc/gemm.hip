@@ -712,32 +712,36 @@ __global__ __launch_bounds__(256) void verify_gemm_kernel(const u32x4* __restric
 // registers -> exact fp16 dequant -> MFMA A operand, never through LDS; only the activation fragments are shared
 // (16 ds_read_b128 per 64 MFMAs = 0.31 KiB per MFMA with the stores).  <= 256 registers so two blocks share a CU:
 // one wave's dequant and LDS waits hide behind the other's MFMAs.
-template <typename P, int AWQ>
+// TT = token tiles per block: 8 (128 tokens) or 9 (144 tokens: T = w d + 1 = 257, 385, 769 split into whole chunks and
+// the one-token tail launch, a full extra pass over the weights, disappears).
+template <typename P, int AWQ, int TT>
 __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __restrict__ wp,
                                                                const unsigned char* __restrict__ meta,
                                                                const u16* __restrict__ x, int ldx,
                                                                float* __restrict__ out, int T, int Tv, int N, int K,
                                                                int S, int epi, GemmFused fx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4* sB = reinterpret_cast<u32x4*>(smem);                        // [2 buf][8 tt][2 s][64]   (64-k steps)
+  u32x4* sB = reinterpret_cast<u32x4*>(smem);                        // [2 buf][TT][2 s][64]   (64-k steps)
+  constexpr int NF = TT * 2;                                         // activation fragments per step
+  constexpr int FPW = (NF + 3) / 4;                                  // staged per wave
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int nblk = N / 256;
-  const int nchunk = (Tv + 127) / 128;
+  const int nchunk = (Tv + TT * 16 - 1) / (TT * 16);
   const int nb = blockIdx.x % nblk;
   const int tc = (blockIdx.x / nblk) % nchunk;
   const int sp = blockIdx.x / (nblk * nchunk);
   const int KB = K / 128;
   const int per = (KB + S - 1) / S;
   const int ks0 = 2 * sp * per, ks1 = 2 * min(KB, sp * per + per);   // 64-k steps
-  const int t0 = tc * 128;
+  const int t0 = tc * TT * 16;
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][TT];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const long tile_base = ((long)(nb * 4 + wv) * KB) * 4;             // int4 tile order [N/64][K/128][4]
   const unsigned* wbase = reinterpret_cast<const unsigned*>(wp + tile_base * 64 + lane);
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
   uint2 ra[4];                                                       // int4: the two dwords of this 64-k half, per n-tile
   unsigned rm[4];
   u32x4 rd[AWQ ? 1 : 4][2];                                          // dense: the two 16 x 32 tiles of this step, per n-tile
-  u32x4 rb[4];
+  u32x4 rb[FPW];
   auto gload = [&](int ks) {
     const int kb = ks >> 1, hf = ks & 1;
 #pragma unroll
@@ -761,16 +765,17 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = wv * 4 + i, tt = f >> 1, sx = f & 1;
+    for (int i = 0; i < FPW; ++i) {
+      const int f = i * 4 + wv, tt = f >> 1, sx = f & 1;
       const int tok = t0 + tt * 16 + j;
       const u32x4 z = {0u, 0u, 0u, 0u};
-      rb[i] = (tok < Tv) ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + ks * 64 + sx * 32 + g * 8) : z;
+      rb[i] = (tok < Tv && f < NF) ? *reinterpret_cast<const u32x4*>(x + (long)tok * ldx + ks * 64 + sx * 32 + g * 8) : z;
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sB[(buf * 16 + wv * 4 + i) * 64 + lane] = rb[i];
+    for (int i = 0; i < FPW; ++i)
+      if (NF % 4 == 0 || i * 4 + wv < NF) sB[(buf * NF + i * 4 + wv) * 64 + lane] = rb[i];
   };
 
   if (ks0 < ks1) {
@@ -809,13 +814,13 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
     }
     if (ks + 1 < ks1) gload(ks + 1);
     // activation fragments: the read for fragment i+1 is in flight while fragment i feeds 4 MFMAs
-    const u32x4* sb = sB + (buf * 16) * 64 + lane;
+    const u32x4* sb = sB + (buf * NF) * 64 + lane;
     u32x4 bcur = sb[0];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NF; ++i) {
       const int t = i >> 1, sx = i & 1;
       u32x4 bnext = bcur;
-      if (i + 1 < 16) bnext = sb[(i + 1) * 64];
+      if (i + 1 < NF) bnext = sb[(i + 1) * 64];
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bcur, acc[q][t]);
       bcur = bnext;
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
   }
 
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < TT; ++t) {
     const int tok = t0 + t * 16 + j;
     if (tok >= Tv) continue;
     float inv = 1.f;
@@ -855,18 +860,25 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
 
 template <typename P, int AWQ>
 static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Tv, int N,
-                         int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
+                         int K, int S, int epi, const GemmFused& fx, hipStream_t st, bool tt9 = false) {
   const int nchunk = (Tv + 127) / 128;
   if constexpr (AWQ != 1) {
     static const bool plain = getenv("UMB_VGEMM_PLAIN") != nullptr;  // diagnostic: the LDS-shared 128 x 128 kernel
     // 256-row blocks: only when they still give every CU a block (small layers keep the 128-row kernel's finer grid)
     if (!plain && N % 256 == 0 && (N / 256) * nchunk * S >= 256) {
-      hipLaunchKernelGGL((verify_gemm_r_kernel<P, AWQ>), dim3((unsigned)((N / 256) * nchunk * S)), dim3(256),
-                         (size_t)2 * 16 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv, N,
-                         K, S, epi, fx);
+      if (tt9) {
+        hipLaunchKernelGGL((verify_gemm_r_kernel<P, AWQ, 9>), dim3((unsigned)((N / 256) * ((Tv + 143) / 144) * S)),
+                           dim3(256), (size_t)2 * 18 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx,
+                           out, T, Tv, N, K, S, epi, fx);
+      } else {
+        hipLaunchKernelGGL((verify_gemm_r_kernel<P, AWQ, 8>), dim3((unsigned)((N / 256) * nchunk * S)), dim3(256),
+                           (size_t)2 * 16 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Tv,
+                           N, K, S, epi, fx);
+      }
       UMB_LAUNCH_CHECK();
       return UMB_OK;
     }
+    if (tt9) return UMB_EINVAL;                                      // caller checks r_kernel_ok() first
   }
   const size_t smem = (size_t)(2 * 8 * 2 + 2 * 8 * 2) * 64 * 16;     // 64 KiB
   hipLaunchKernelGGL((verify_gemm_kernel<P, AWQ>), dim3((unsigned)((N / 128) * nchunk * S)), dim3(256), smem, st,
@@ -935,6 +947,11 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     static const bool no_vgemm = getenv("UMB_NO_VGEMM") != nullptr;     // diagnostic: 64-token chunks only
     if (T > 64 && N % 128 == 0 && epi <= EPI_SILU && !no_vgemm) {
       const int rem = T % 128;
+      // T = w d + 1 (257, 385, 769 ...): 144-token blocks swallow the short tail in the same number of chunks
+      const int nc9 = (T + 143) / 144;
+      if (rem >= 1 && rem <= 64 && nc9 == T / 128 && N % 256 == 0 && (N / 256) * nc9 * S >= 256 &&
+          getenv("UMB_VGEMM_PLAIN") == nullptr)
+        return launch_verify<P, AWQ>(wp, meta, x, ldx, out, T, T, N, K, S, epi, fx0, st, /*tt9=*/true);
       tdone = (rem == 0 || rem > 64) ? T : T - rem;                  // a tail of <= 64 tokens is HBM-bound: skinny kernel
       const int rc = launch_verify<P, AWQ>(wp, meta, x, ldx, out, T, tdone, N, K, S, epi, fx0, st);
       if (rc || tdone == T) return rc;
