@@ -42,11 +42,13 @@ out = torch.empty(T, Hq, D, dtype=dt, device=dev)
 po = torch.empty(splits * T * Hq * D, dtype=torch.float32, device=dev)
 pml = torch.empty(splits * T * Hq * 2, dtype=torch.float32, device=dev)
 pre = torch.tensor([a.prefix], dtype=torch.int32, device=dev)
+# counters -> the single-launch kernel the models use (UMB_ATTN_SPLIT=1 forces the split + combine pair)
+cnt = torch.zeros(Hkv * ((T * (Hq // Hkv) + 15) // 16) + 64, dtype=torch.int32, device=dev)
 
 
 def launch():
     _lib.call("umb_tree_attn", out, q, kc, vt, po, pml, pre, bits, 0 if bits is None else bits.shape[1], T, T, Hq, Hkv, D, Lmax,
-              chunk, splits, D ** -0.5, None, _lib.dtype_code(dt))
+              chunk, splits, D ** -0.5, cnt, _lib.dtype_code(dt))
 
 
 s = torch.cuda.Stream()

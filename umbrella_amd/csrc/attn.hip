@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
   const int kv_end = prefix + n_mask_keys;
   const int k_lo = blockIdx.z * KBK;
   if (k_lo >= kv_end) return;                                  // whole block: span not in use yet
-  const int k_hi = min(kv_end, k_lo + KBK);
+  int k_hi = min(kv_end, k_lo + KBK);
   const u16* kbase = kc + (long)h * Lmax * D;
   const long LV = VT_LD(Lmax);
   const u16* vbase = vt + (long)h * D * LV;
@@ -216,6 +216,23 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
   f32x4 o[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Keys past the last one any row of this tile can see are never touched: in a tree (and in causal prefill) a node
+  // sees no later node, so the tile of tokens [t0, t1] stops at prefix + t1 + 1 -- half of the tree keys on average.
+  if (n_mask_keys > 64) {                                        // small trees: nothing worth skipping, no scan
+    int top = -1;                                                // highest visible tree key of this lane's row
+    if (row_ok && mask_bits) {
+      const unsigned long long* mrow = mask_bits + (long)t * mask_words;
+      for (int w = mask_words - 1; w >= 0; --w) {
+        const unsigned long long x = mrow[w];
+        if (x) { top = w * 64 + 63 - __clzll((long long)x); break; }
+      }
+    } else if (row_ok) {
+      top = t;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) top = max(top, __shfl_xor(top, off, 64));
+    k_hi = min(k_hi, prefix + top + 1);
+  }
 
   auto load_k = [&](int k0, u32x4 (&ak)[2][DS]) {
 #pragma unroll
@@ -244,25 +261,22 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
       st[s] = acc;
     }
     const int bfirst = k0 + gq * 8 - prefix;
-    unsigned vbits = 0xffu;
-    if (k0 + 32 > prefix) {
+    unsigned vbits = 0xffu;                                     // bit e: key k0 + gq*8 + e visible to this row
+    if (k0 + 32 > prefix && bfirst > -8) {
+      const int neg = max(-bfirst, 0);                           // leading keys that still belong to the prefix
       if (mask_bits) {
-        const int lo = max(bfirst, 0), wi = lo >> 6;
+        // the 8 mask bits starting at max(bfirst, 0), funnel-shifted out of two adjacent words
+        const int lo = max(bfirst, 0), wi = lo >> 6, sh = lo & 63;
         const unsigned long long* mrow = mask_bits + (long)t * mask_words;
         const unsigned long long w0 = mrow[min(wi, mask_words - 1)], w1 = mrow[min(wi + 1, mask_words - 1)];
-        vbits = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int b = bfirst + e;
-          unsigned v = 1u;
-          if (b >= 0) v = (unsigned)((((b >> 6) == wi ? w0 : w1) >> (b & 63)) & 1ull);
-          vbits |= v << e;
-        }
+        unsigned long long x = w0 >> sh;
+        if (sh) x |= w1 << (64 - sh);
+        vbits = (unsigned)x & 0xffu;
       } else {
-        vbits = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vbits |= (unsigned)(bfirst + e <= t) << e;
+        const int n = min(max(t - max(bfirst, 0) + 1, 0), 8);      // causal: tree keys 0 .. t
+        vbits = (1u << n) - 1u;
       }
+      vbits = ((vbits << neg) | ((1u << neg) - 1u)) & 0xffu;
     }
     float pv[8];
     float tmax = NEG_BIG;
