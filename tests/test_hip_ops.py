@@ -201,6 +201,51 @@ def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix, path):
     assert err < tol, float(err)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,prefix,Lmax", [(257, 128, 1024), (300, 77, 4096), (769, 128, 4096), (200, 2300, 4096)])
+@pytest.mark.parametrize("kind", ["tree", "arbitrary"])
+def test_tree_attention_wide(dev, dtype, T, prefix, Lmax, kind):
+    """Wide trees (several mask words, several query tiles per kv head) through the single-launch kernel, which ends
+    each query tile at the last key its rows can see.  "arbitrary": a random mask in which rows also see LATER keys
+    (not a tree) -- the end of a tile is taken from the mask bits, not assumed from the row index."""
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import pack_mask_bits
+    Hq, Hkv, D = 16, 2, 128
+    rs = np.random.RandomState(T + prefix)
+    g = torch.Generator().manual_seed(T * 7 + prefix)
+    S = prefix + T
+    q = torch.randn(T, Hq, D, generator=g).to(dtype)
+    k = torch.randn(S, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(S, Hkv, D, generator=g).to(dtype)
+    if kind == "tree":
+        tm = _tree_mask(T, rs)
+    else:
+        tm = torch.from_numpy(rs.rand(T, T) < 0.05)
+        tm[torch.arange(T), torch.arange(T)] = True
+        tm[5] = False                                                         # a row that sees prefix keys only
+        tm[5, 0] = prefix == 0
+        tm[T // 2, T - 1] = True                                              # ... and one that sees the very last key
+    mask = torch.cat([torch.ones(T, prefix, dtype=torch.bool), tm], dim=1)
+    ref = O.masked_attention(q.float(), k.float(), v.float(), mask)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype)
+    vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype)
+    kc[:, :S] = k.permute(1, 0, 2)
+    vt[:, :, :S] = v.permute(1, 2, 0)
+    bits = pack_mask_bits(tm).to(dev)
+    spans = (Lmax + 2047) // 2048
+    out = torch.empty(T, Hq, D, dtype=dtype, device=dev)
+    po = torch.empty(spans * T * Hq * D, dtype=torch.float32, device=dev)
+    pml = torch.empty(spans * T * Hq * 2, dtype=torch.float32, device=dev)
+    pre = torch.tensor([prefix], dtype=torch.int32, device=dev)
+    counters = torch.zeros(Hkv * ((T * (Hq // Hkv) + 15) // 16), dtype=torch.int32, device=dev)
+    _lib.call("umb_tree_attn", out, q.to(dev), kc.to(dev), vt.to(dev), po, pml, pre, bits, bits.shape[1], T, T, Hq, Hkv,
+              D, Lmax, 2048, spans, 1.0 / math.sqrt(D), counters, _lib.dtype_code(dtype))
+    assert int(counters.abs().sum()) == 0
+    tol = 0.03 if dtype == torch.bfloat16 else 0.004
+    err = (out.cpu().float() - ref).abs().max()
+    assert err < tol, float(err)
+
+
 def test_argmax_and_topk(dev):
     from umbrella_amd import _lib
     g = torch.Generator().manual_seed(4)
