@@ -204,13 +204,14 @@ def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix, path):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("T,prefix,Lmax", [(257, 128, 1024), (300, 77, 4096), (769, 128, 4096), (200, 2300, 4096)])
 @pytest.mark.parametrize("kind", ["tree", "arbitrary"])
-def test_tree_attention_wide(dev, dtype, T, prefix, Lmax, kind):
+@pytest.mark.parametrize("Hq,Hkv", [(16, 2), (64, 8)])
+def test_tree_attention_wide(dev, dtype, T, prefix, Lmax, kind, Hq, Hkv):
     """Wide trees (several mask words, several query tiles per kv head) through the single-launch kernel, which ends
     each query tile at the last key its rows can see.  "arbitrary": a random mask in which rows also see LATER keys
     (not a tree) -- the end of a tile is taken from the mask bits, not assumed from the row index."""
     from umbrella_amd import _lib
     from umbrella_amd.models.llama import pack_mask_bits
-    Hq, Hkv, D = 16, 2, 128
+    D = 128                                  # 2 or 8 kv heads x 17 .. 385 query tiles: 8, 2 and 1 waves per tile
     rs = np.random.RandomState(T + prefix)
     g = torch.Generator().manual_seed(T * 7 + prefix)
     S = prefix + T

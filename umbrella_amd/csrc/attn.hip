@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
 // (head, tile) counter combines them (same protocol as the split-K epilogues).  grid = (Hkv, query tiles, spans):
 // kv head h stays on XCD h % 8.
 template <typename P, int D, int NW>
-__global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
+__global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
                                                          const u16* __restrict__ vt, const int* __restrict__ prefix_p,
                                                          const unsigned long long* __restrict__ mask_bits,
                                                          int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
@@ -192,7 +192,8 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, gq = lane >> 4;
-  const int h = blockIdx.x, qt = blockIdx.y;
+  // last query tiles first: they see the most keys (a node never sees a later one), so the long blocks start early
+  const int h = blockIdx.x, qt = gridDim.y - 1 - blockIdx.y;
   const int g = Hq / Hkv;
   const int nrows = T * g;
   const int prefix = *prefix_p;
@@ -323,40 +324,52 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
   }
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
-  // ---- merge the eight wave partials through LDS
+  // ---- merge the NW wave partials through LDS; wave w finishes the d-tiles w, w + NW, ...
+  constexpr int NDT = (DT + NW - 1) / NW;
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) so[wv][dt][lane] = o[dt];
   if (gq == 0) { sm[wv][j] = m; sl[wv][j] = l; }
   __syncthreads();
   const int nsp = (kv_end + KBK - 1) / KBK;                     // span blocks that did not exit above
   float M = NEG_BIG, L = 0.f;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (wv < DT) {
+  f32x4 acc[NDT];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j]);
+  for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j]);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float wt = __expf(sm[w][j] - M);
-      L += sl[w][j] * wt;
-      acc += so[w][wv][lane] * wt;
-    }
+  for (int c = 0; c < NDT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float wt = __expf(sm[w][j] - M);
+    L += sl[w][j] * wt;
+#pragma unroll
+    for (int c = 0; c < NDT; ++c)
+      if (wv + c * NW < DT) acc[c] += so[w][wv + c * NW][lane] * wt;
   }
   const long orow = (long)t * Hq + hq;
+  auto store_out = [&](const f32x4& a, float inv, int dt) {
+    uint2 o2;
+    o2.x = pack2<P>(a[0] * inv, a[1] * inv); o2.y = pack2<P>(a[2] * inv, a[3] * inv);
+    *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
+  };
   if (nsp == 1) {
-    if (wv < DT && row_ok) {
+    if (row_ok) {
       const float inv = L > 0.f ? 1.f / L : 0.f;
-      uint2 o2;
-      o2.x = pack2<P>(acc[0] * inv, acc[1] * inv); o2.y = pack2<P>(acc[2] * inv, acc[3] * inv);
-      *reinterpret_cast<uint2*>(out + orow * D + wv * 16 + gq * 4) = o2;
+#pragma unroll
+      for (int c = 0; c < NDT; ++c)
+        if (wv + c * NW < DT) store_out(acc[c], inv, wv + c * NW);
     }
     return;
   }
   // ---- more than one span: publish (M, L, acc) write-through, last arriver combines
   const long rows_all = (long)T * Hq;
-  if (wv < DT && row_ok) {
+  if (row_ok) {
     const long prow = (long)blockIdx.z * rows_all + orow;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs_o, (int)((prow * D + wv * 16 + gq * 4) * 4), 0, 16);
+#pragma unroll
+    for (int c = 0; c < NDT; ++c)
+      if (wv + c * NW < DT)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[c]), rs_o,
+                                               (int)((prow * D + (wv + c * NW) * 16 + gq * 4) * 4), 0, 16);
     if (wv == 0 && gq == 0) {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
@@ -378,21 +391,26 @@ __global__ __launch_bounds__(64 * NW) void tree_attn1_kernel(const u16* __restri
     s_last = last;
   }
   __syncthreads();
-  if (!s_last || wv >= DT || !row_ok) return;
+  if (!s_last || !row_ok) return;
   float Mg = NEG_BIG;
   for (int s2 = 0; s2 < nsp; ++s2) Mg = fmaxf(Mg, pml[(s2 * rows_all + orow) * 2]);
   float Lg = 0.f;
-  f32x4 ag = {0.f, 0.f, 0.f, 0.f};
   for (int s2 = 0; s2 < nsp; ++s2) {
     const long pr = s2 * rows_all + orow;
-    const float wt = __expf(pml[pr * 2] - Mg);
-    Lg += pml[pr * 2 + 1] * wt;
-    ag += *reinterpret_cast<const f32x4*>(po + pr * D + wv * 16 + gq * 4) * wt;
+    Lg += pml[pr * 2 + 1] * __expf(pml[pr * 2] - Mg);
   }
   const float inv = Lg > 0.f ? 1.f / Lg : 0.f;
-  uint2 o2;
-  o2.x = pack2<P>(ag[0] * inv, ag[1] * inv); o2.y = pack2<P>(ag[2] * inv, ag[3] * inv);
-  *reinterpret_cast<uint2*>(out + orow * D + wv * 16 + gq * 4) = o2;
+#pragma unroll
+  for (int c = 0; c < NDT; ++c) {
+    const int dt = wv + c * NW;
+    if (dt >= DT) continue;
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < nsp; ++s2) {
+      const long pr = s2 * rows_all + orow;
+      ag += *reinterpret_cast<const f32x4*>(po + pr * D + dt * 16 + gq * 4) * __expf(pml[pr * 2] - Mg);
+    }
+    store_out(ag, inv, dt);
+  }
 }
 
 // merge the per-split partials: one wave per (t, hq) row
@@ -448,17 +466,27 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
   const int KBK = 2048;
   const int spans = (Lmax + KBK - 1) / KBK;
   if ((counters || spans == 1) && nqt <= 65535 && spans <= max_splits && !no_single) {
-    const dim3 grid1(Hkv, nqt, spans), block1(512);
-#define ATT1_(DD)                                                                                                 \
-  hipLaunchKernelGGL((tree_attn1_kernel<P, DD, 8>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,      \
+    // Waves per (kv head, query tile): eight while the tiles are few (narrow trees: the keys of a tile are spread over
+    // the waves and merged in LDS); with many tiles the chip is filled by tiles instead and a wave walks more keys,
+    // so the per-block prologue and merge are paid 4x / 8x less often.
+    static const int nw_env = getenv("UMB_ATTN_NW") ? atoi(getenv("UMB_ATTN_NW")) : 0;
+    const int nblk = Hkv * nqt;
+    const int nw = nw_env ? nw_env : nblk >= 2048 ? 1 : nblk >= 512 ? 2 : 8;
+    const dim3 grid1(Hkv, nqt, spans), block1(64 * nw);
+#define ATT1N_(DD, NWV)                                                                                           \
+  hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,    \
                      (const u16*)vt_cache, prefix_len, (const unsigned long long*)mask_bits, mask_words,           \
                      n_mask_keys, T, Hq, Hkv, Lmax, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters)
+#define ATT1_(DD)                                                                                                 \
+  if (nw == 1) { ATT1N_(DD, 1); } else if (nw == 2) { ATT1N_(DD, 2); } else if (nw == 4) { ATT1N_(DD, 4); }       \
+  else { ATT1N_(DD, 8); }
     DISPATCH_DTYPE(dtype, {
-      if (D == 128) { ATT1_(128); }
-      else if (D == 64) { ATT1_(64); }
-      else { ATT1_(32); }
+      if (D == 128) { ATT1_(128) }
+      else if (D == 64) { ATT1_(64) }
+      else { ATT1_(32) }
     })
 #undef ATT1_
+#undef ATT1N_
     UMB_LAUNCH_CHECK();
     return UMB_OK;
   }

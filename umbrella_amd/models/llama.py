@@ -119,8 +119,8 @@ def pack_mask_bits(mask: torch.Tensor) -> torch.Tensor:
 
 class Llama(LLMBase):
     CHUNK = 64          # rows of the default workspace (tree / generic forwards)
-    PREFILL_CHUNK = 256  # prompt tokens per forward when the workspace allows: the matrix-bound verify GEMM streams the
-                         # weights once per chunk (70B-AWQ: 3.2 k tok/s at 64, 4.8 k at 256, 5.0 k at 512)
+    PREFILL_CHUNK = 512  # prompt tokens per forward when the workspace allows: the matrix-bound verify GEMM streams the
+                         # weights once per chunk (70B-AWQ, 2048-token prompt: 3.6 k tok/s at 128, 5.4 k at 256, 6.1 k at 512)
 
     def __init__(self, model_name: str, batch_size: int = 1, max_length: int = 256, device: str = "cuda:0",
                  dtype=torch.float16, offload: bool = False, cuda_graph: bool = False, state_dict=None,
