@@ -12,7 +12,7 @@ m.alloc()
 g = torch.Generator().manual_seed(0)
 for P in (128, 512, 2048):
     ids = torch.randint(3, 128000, (P,), generator=g).int().cuda()
-    for chunk in (64, 128, 256, 512):
+    for chunk in (128, 256, 512, 1024):
         m.PREFILL_CHUNK = chunk
         m.reserve(chunk, logit_rows=64)
         m.clear(); m.prefill_tokens(ids, 0); torch.cuda.synchronize()

@@ -323,7 +323,7 @@ def test_generate_stream_matches_generate(dev):
 
 
 def test_long_context_spans_and_wide_prefill(dev):
-    """A 2150-token prompt on a 4096-slot engine: prefill runs in 512-token chunks through the T > 64 kernels, the
+    """A 2150-token prompt on a 4096-slot engine: prefill runs in 1024-token chunks through the T > 64 kernels, the
     tree attention crosses into its second 2048-key span (last-arriver merge) during decoding, and the generated
     tokens are still the fp32 oracle target's greedy choices."""
     from hip_helpers import check_greedy, static_engine
