@@ -13,6 +13,7 @@ T = int(os.environ.get("T", "13"))
 dtype = torch.float16 if os.environ.get("DT", "fp16") == "fp16" else torch.bfloat16
 gen = torch.Generator(device=dev).manual_seed(0)
 SHAPES = {"70b": [("qkv", 10240, 8192, 1, 0), ("o", 8192, 8192, 1, 0), ("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 1, 0)],
+          "70b-dense": [("qkv", 10240, 8192, 0, 0), ("o", 8192, 8192, 0, 0), ("gu", 57344, 8192, 0, 1), ("down", 8192, 28672, 0, 0)],
           "1b": [("qkv", 3072, 2048, 0, 0), ("o", 2048, 2048, 0, 0), ("gu", 16384, 2048, 0, 1), ("down", 2048, 8192, 0, 0),
                  ("head", 128256, 2048, 0, 0)]}
 for model in sys.argv[1:] or ["70b", "1b"]:

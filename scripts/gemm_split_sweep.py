@@ -10,7 +10,7 @@ from umbrella_amd.models.synthetic import synth_awq_tensors
 dev = "cuda:0"; T = int(os.environ.get("T", "13"))
 gen = torch.Generator(device=dev).manual_seed(0)
 SHAPES = [("70b qkv", 10240, 8192, 1), ("70b o", 8192, 8192, 1), ("70b down", 8192, 28672, 1),
-          ("8b-awq qkv", 6144, 4096, 1), ("8b-awq o", 4096, 4096, 1), ("8b-awq down", 4096, 14336, 1),
+          ("8b-awq gu", 28672, 4096, 1), ("8b-awq qkv", 6144, 4096, 1), ("8b-awq o", 4096, 4096, 1), ("8b-awq down", 4096, 14336, 1),
           ("8b qkv", 6144, 4096, 0), ("8b o", 4096, 4096, 0), ("8b down", 4096, 14336, 0),
           ("1b qkv", 3072, 2048, 0), ("1b o", 2048, 2048, 0), ("1b down", 2048, 8192, 0)]
 only = sys.argv[1:] 
