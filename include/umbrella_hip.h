@@ -47,6 +47,10 @@ int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzer
 /* ------------------------------------------------------------------ linear layers */
 /* split plan for a [N][K] linear: depends on (N, K, format) only, never on T. */
 void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out);
+/* split count the model runtime uses for a T-token forward of that linear: the plan's S for T <= 64 (so a token's
+ * result does not depend on its batch mates there); for wider forwards (tree verify, prompt chunks) the S <= plan
+ * that fills the 2 x 256 block slots of the register-resident verify kernel about once. */
+int umb_gemm_wide_split(int T, int N, int S_plan);
 /* out[S][T][N] (fp32 split-K partials) = x[T][K] (row stride ldx) . W^T
  * replaces F.linear (umbrella/models/llama.py:89-91,103,107-111,133) and
  * AwqLinear.apply -> awq_ext.gemm_forward_cuda / dequantize_weights_cuda

@@ -80,6 +80,7 @@ SIGNATURES = {
     "umb_repack_dense": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_plan": [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)],
+    "umb_gemm_wide_split": [_I, _I, _I],
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_fused": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(UmbGemmFused), _I, _P],
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],

@@ -890,6 +890,21 @@ static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx
   return UMB_OK;
 }
 
+// Split count for a wide (T > 64) forward.  The register-resident verify kernel runs two 256-row x 128/144-token
+// blocks per CU, i.e. 512 block slots: S is chosen so that (N/256) * chunks * S lands just under 512 (one full round;
+// measured optimum on the 70B shapes: T = 257 -> 6 / 8 / 8 for qkv / o / down, T = 769 -> 2, T = 1024 -> 3 / 2 / 2).
+// More splits only add fp32 partial traffic (S * T * N * 8 bytes per GEMM), fewer leave CUs with one wave per SIMD.
+extern "C" int umb_gemm_wide_split(int T, int N, int S_plan) {
+  if (T <= 64 || S_plan <= 1) return S_plan;
+  const int rem = T % 128, nc9 = (T + 143) / 144;
+  const bool tail = rem >= 1 && rem <= 64;
+  const int nchunk = (tail && nc9 == T / 128) ? nc9 : tail ? T / 128 : (T + 127) / 128;
+  const int b0 = max(1, (N / 256) * max(1, nchunk));
+  int S = 512 / b0;
+  if (S < 2) S = b0 <= 341 ? 3 : b0 <= 512 ? 2 : 1;
+  return max(1, min(S, S_plan));
+}
+
 // ------------------------------------------------------------------ host side
 // (R, S) depend on (N, K, format) only -- never on T -- so a token's result is
 // independent of how many other tokens share the launch.

@@ -12,8 +12,8 @@
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
 // split count actually used: the plan's S (a function of the layer shape only, so T <= 64 results are batch
-// invariant); the wide verify (T > 64) has plenty of token-chunk parallelism and keeps the partial traffic down
-static inline int eff_s(const UmbLinear& l, int T) { return (T > 64 && l.S > 4) ? 4 : l.S; }
+// invariant); the wide verify (T > 64) takes the S <= plan that fills the verify kernel's block slots once (gemm.hip)
+static inline int eff_s(const UmbLinear& l, int T) { return umb_gemm_wide_split(T, l.N, l.S); }
 
 static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int T, int dtype, hipStream_t st, int epi,
                       const UmbGemmFused* fx) {

@@ -120,8 +120,8 @@ def pack_mask_bits(mask: torch.Tensor) -> torch.Tensor:
 class Llama(LLMBase):
     CHUNK = 64          # rows of the default workspace (tree / generic forwards)
     PREFILL_CHUNK = 1024  # prompt tokens per forward when the workspace allows: the matrix-bound verify GEMM streams the
-                          # weights once per chunk (70B-AWQ, 2048-token prompt: 3.6 k tok/s at 128, 5.4 k at 256, 6.1 k at
-                          # 512, 6.6 k at 1024; 1B: 53 k / 94 k / 155 k / 211 k).  1024 = rows of the attention counters.
+                          # weights once per chunk (70B-AWQ, 2048-token prompt: 4.2 k tok/s at 128, 6.1 k at 256, 6.7 k at
+                          # 512, 7.0 k at 1024; 1B: 53 k / 94 k / 155 k / 211 k).  1024 = rows of the attention counters.
 
     def __init__(self, model_name: str, batch_size: int = 1, max_length: int = 256, device: str = "cuda:0",
                  dtype=torch.float16, offload: bool = False, cuda_graph: bool = False, state_dict=None,
