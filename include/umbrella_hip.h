@@ -126,6 +126,12 @@ int umb_argmax_rows(int* out, const float* logits, int rows, int V, umb_stream_t
  * placement tokens_all[*n_ptr + child_start[row] + r] = idx[r], r < child_cnt[row] (static:115-123,279-281) */
 int umb_topk_rows(int* out_idx, float* out_val, const float* logits, int rows, int V, int k, int* tokens_all,
                   const int* n_ptr, const int* child_start, const int* child_cnt, umb_stream_t stream);
+/* the same with each row's vocabulary split over 16 blocks (a single block reads a row at ~50 GB/s); workspace =
+ * 4096 bytes of zeroed row counters (self-resetting) + rows * 16 * k * 8 bytes; falls back to umb_topk_rows when the
+ * workspace is NULL / too small or V < 16384. */
+int umb_topk_rows_ws(int* out_idx, float* out_val, const float* logits, int rows, int V, int k, int* tokens_all,
+                     const int* n_ptr, const int* child_start, const int* child_cnt, void* workspace,
+                     size_t workspace_bytes, umb_stream_t stream);
 /* verification sampling, one token per tree node (static_speculation_engine.py:298-310,
  * dynamic_speculation_engine.py:266-281; helpers speculation_utils.py:340-352; replaces
  * flashinfer.sampling.top_k_top_p_sampling_from_logits / top_p_renorm_prob + torch.multinomial):

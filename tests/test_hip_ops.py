@@ -280,6 +280,48 @@ def test_argmax_and_topk(dev):
     assert idx.cpu().tolist() == [list(range(8))] * 2
 
 
+@pytest.mark.parametrize("V", [128256, 151936, 32000, 16388])
+def test_topk_split_matches_single_block(dev, V):
+    """umb_topk_rows_ws (vocabulary of a row split over 16 blocks, last arriver merges) == umb_topk_rows bit for bit:
+    values, indices, tie order, Sequoia child placement; counters reset themselves; flat rows (all ties) included."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(V)
+    rows = 9
+    logits = torch.randn(rows, V, generator=g).bfloat16().float()
+    logits[3] = 0.0                                              # all equal: the k lowest indices
+    logits[4, V - 1] = logits[4, 0] = 11.0                        # tie across the first and the last slice
+    logits[5, :] = -float("inf")
+    logits[5, 7] = 1.0                                           # one finite entry, the rest -inf (ties among -inf)
+    d = logits.to(dev)
+    for k in (1, 4, 32, 64):
+        ws = torch.zeros(4096 + rows * 16 * k * 8, dtype=torch.uint8, device=dev)
+        ia, ib = (torch.empty(rows, k, dtype=torch.int32, device=dev) for _ in range(2))
+        va, vb = (torch.empty(rows, k, dtype=torch.float32, device=dev) for _ in range(2))
+        _lib.call("umb_topk_rows", ia, va, d, rows, V, k, None, None, None, None)
+        for _ in range(2):                                       # second launch: the counters have reset themselves
+            ib.fill_(-1)
+            _lib.call("umb_topk_rows_ws", ib, vb, d, rows, V, k, None, None, None, None, ws, ws.numel())
+            assert torch.equal(ia.cpu(), ib.cpu()), k
+            assert torch.equal(va.cpu(), vb.cpu()), k
+        assert int(ws[:4096].sum()) == 0
+    # child placement through the split kernel
+    k = 4
+    ws = torch.zeros(4096 + rows * 16 * k * 8, dtype=torch.uint8, device=dev)
+    cs = torch.arange(rows, dtype=torch.int32, device=dev) * 4 + 1
+    cc = torch.tensor([4, 0, 2, 1, 3, 4, 0, 1, 2], dtype=torch.int32, device=dev)
+    n = torch.tensor([10], dtype=torch.int32, device=dev)
+    ta, tb = (torch.full((64,), -7, dtype=torch.int32, device=dev) for _ in range(2))
+    _lib.call("umb_topk_rows", None, None, d, rows, V, k, ta, n, cs, cc)
+    _lib.call("umb_topk_rows_ws", None, None, d, rows, V, k, tb, n, cs, cc, ws, ws.numel())
+    assert torch.equal(ta.cpu(), tb.cpu())
+    # too small a workspace falls back to the single-block kernel
+    ib = torch.empty(rows, k, dtype=torch.int32, device=dev)
+    ia = torch.empty(rows, k, dtype=torch.int32, device=dev)
+    _lib.call("umb_topk_rows", ia, None, d, rows, V, k, None, None, None, None)
+    _lib.call("umb_topk_rows_ws", ib, None, d, rows, V, k, None, None, None, None, ws, 100)
+    assert torch.equal(ia.cpu(), ib.cpu())
+
+
 def test_topk_places_sequoia_children(dev):
     from umbrella_amd import _lib
     g = torch.Generator().manual_seed(5)

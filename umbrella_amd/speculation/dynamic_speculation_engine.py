@@ -44,6 +44,8 @@ class DynamicSpeculationEngine(HipEngine):
         self.mask_bits[0, 0] = 1                                   # root attends itself
         self.top_idx = torch.zeros(W * self.num_beams, dtype=torch.int32, device=dev)
         self.top_val = torch.zeros(W * self.num_beams, dtype=torch.float32, device=dev)
+        # row counters (zeroed once, self-resetting) + per-part keys of the split top-k (umb_topk_rows_ws)
+        self.topk_ws = torch.zeros(4096 + W * 16 * self.num_beams * 8, dtype=torch.uint8, device=dev)
         self.draft_rows = W
         self._load_models(dict(offload=False), dict(offload=bool(self.offload_target)))
         if getattr(self.target_model, "_off", None) is not None:
@@ -67,8 +69,8 @@ class DynamicSpeculationEngine(HipEngine):
                                head_from=w if last else 0)
             if last:
                 break
-            _lib.call("umb_topk_rows", self.top_idx, self.top_val, d.logits_buffer, w, self.vocab_size, B,
-                      None, None, None, None)
+            _lib.call("umb_topk_rows_ws", self.top_idx, self.top_val, d.logits_buffer, w, self.vocab_size, B,
+                      None, None, None, None, self.topk_ws, self.topk_ws.numel())
             _lib.call("umb_beam_expand", self.top_idx, self.top_val, w, B, W, off, self.tree_score, self.parents,
                       self.tokens, self.n_dev, self.mask_bits, self.mask_words)
 

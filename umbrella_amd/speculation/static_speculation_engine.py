@@ -79,6 +79,9 @@ class StaticSpeculationEngine(HipEngine):
                                     child_start=torch.tensor(starts, dtype=torch.int32, device=dev),
                                     child_cnt=torch.tensor(self.branch_lists[i] if k else [0] * w, dtype=torch.int32, device=dev)))
         self.draft_rows = max(l["w"] for l in self.levels)
+        # row counters (zeroed once, self-resetting) + per-part keys of the split top-k (umb_topk_rows_ws)
+        self.topk_ws = torch.zeros(4096 + max(l["w"] * max(l["k"], 1) for l in self.levels) * 16 * 8, dtype=torch.uint8,
+                                   device=dev)
         self._load_models(dict(offload=False, cuda_graph=True), dict(offload=False))
         self._alloc_state(T, self.tree_depth)
         self.override_tbl = torch.full((T,), -1, dtype=torch.int32, device=dev)
@@ -142,8 +145,9 @@ class StaticSpeculationEngine(HipEngine):
                 d.forward_tree(self.tokens, self.n_dev, self.depth, lv["off"], lv["w"], self.mask_bits,
                                self.mask_words, head_from=0 if has_head else lv["w"])
             if has_head:
-                _lib.call("umb_topk_rows", None, None, d.logits_buffer, lv["w"], self.vocab_size, lv["k"],
-                          self.tokens, self.n_dev, lv["child_start"], lv["child_cnt"])
+                _lib.call("umb_topk_rows_ws", None, None, d.logits_buffer, lv["w"], self.vocab_size, lv["k"],
+                          self.tokens, self.n_dev, lv["child_start"], lv["child_cnt"], self.topk_ws,
+                          self.topk_ws.numel())
                 if self.enable_override:
                     nxt = lv["off"] + lv["w"]
                     cnt = int(sum(self.branch_lists[self.levels.index(lv)]))
