@@ -13,11 +13,23 @@
 
 // split count actually used: the plan's S (a function of the layer shape only, so T <= 64 results are batch
 // invariant); the wide verify (T > 64) takes the S <= plan that fills the verify kernel's block slots once (gemm.hip)
-static inline int eff_s(const UmbLinear& l, int T) { return umb_gemm_wide_split(T, l.N, l.S); }
+// row_reduce: the partials are summed by reduce_residual_norm, one block per token row, which reads them at a single
+// CU's ~60 GB/s (0.55 us per split at N = 8192) -- worth more than the last splits give the GEMM when K is short
+// (70B o-proj, T = 13: S = 8 -> 4 costs the GEMM +0.4 us and saves the reduce 2.2 us; 70B down, K = 28672, keeps 8;
+// 8B-AWQ down keeps 8 of its planned 16).  A function of the layer shape only, like the plan itself.
+static inline int eff_s(const UmbLinear& l, int T, bool row_reduce = false) {
+  int S = umb_gemm_wide_split(T, l.N, l.S);
+  if (row_reduce && T <= 64) {
+    const int cap = l.K / 1792 > 4 ? l.K / 1792 : 4;
+    const int nblk = l.N / (64 * (l.R > 0 ? l.R : 1));        // 64 R rows per block: never drop below one block per CU
+    if (S > cap && nblk * cap >= 256) S = cap;
+  }
+  return S;
+}
 
 static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int T, int dtype, hipStream_t st, int epi,
-                      const UmbGemmFused* fx) {
-  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, eff_s(l, T), l.R, epi, fx, dtype, st);
+                      const UmbGemmFused* fx, bool row_reduce = false) {
+  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, eff_s(l, T, row_reduce), l.R, epi, fx, dtype, st);
 }
 
 // embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h
@@ -49,12 +61,12 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
                    ws->attn_counters, dt, st));
-  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr));
-  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.o, T), T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr, true));
+  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.o, T, true), T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
   CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
-  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr));
-  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.down, T), T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
+  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr, true));
+  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.down, T, true), T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
                               m->eps, dt, st));
   return UMB_OK;
 }
