@@ -63,8 +63,72 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
   const int t = blockIdx.x;
   const long sstride = (long)T * N;
   float ss = 0.f;
+  if (S <= 8 && N <= 8192) {
+    // Whole row in registers (<= 2 column groups per thread): every load of the kernel -- partials, residual, norm
+    // weight -- is issued before the first add, and the normalised row is produced from registers (no LDS row).
+    const int i0 = threadIdx.x * 4, i1 = i0 + 4096;
+    const bool ok0 = i0 < N, ok1 = i1 < N;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v0[8], v1[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      v0[s2] = (ok0 && s2 < S) ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i0 + (long)s2 * sstride) : z;
+      v1[s2] = (ok1 && s2 < S) ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i1 + (long)s2 * sstride) : z;
+    }
+    const uint2 z2 = {0u, 0u};
+    const uint2 r0 = (residual && ok0) ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i0) : z2;
+    const uint2 r1 = (residual && ok1) ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i1) : z2;
+    const uint2 g0 = (xn_out && ok0) ? *reinterpret_cast<const uint2*>(w + i0) : z2;
+    const uint2 g1 = (xn_out && ok1) ? *reinterpret_cast<const uint2*>(w + i1) : z2;
+    auto finish = [&](const f32x4 (&v)[8], const uint2& r, bool ok, int i) -> uint2 {
+      f32x4 a = v[0];
+#pragma unroll
+      for (int s2 = 1; s2 < 8; ++s2)
+        if (s2 < S) a += v[s2];                                  // fixed order 0..S-1
+      float x0 = rnd<P>(a[0]), x1 = rnd<P>(a[1]), x2 = rnd<P>(a[2]), x3 = rnd<P>(a[3]);
+      if (residual) { x0 += lo_f<P>(r.x); x1 += hi_f<P>(r.x); x2 += lo_f<P>(r.y); x3 += hi_f<P>(r.y); }
+      uint2 o;
+      o.x = pack2<P>(x0, x1); o.y = pack2<P>(x2, x3);
+      if (ok) {
+        if (h_out) *reinterpret_cast<uint2*>(h_out + (long)t * N + i) = o;
+        x0 = lo_f<P>(o.x); x1 = hi_f<P>(o.x); x2 = lo_f<P>(o.y); x3 = hi_f<P>(o.y);
+        ss += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+      }
+      return o;
+    };
+    const uint2 o0 = finish(v0, r0, ok0, i0);
+    const uint2 o1 = finish(v1, r1, ok1, i1);
+    if (!xn_out) return;
+    ss = block_sum<1024>(ss, red);
+    const float inv = rsqrtf(ss / (float)N + eps);
+    auto norm = [&](const uint2& v, const uint2& g, int i) {
+      uint2 o;
+      o.x = pack2<P>(lo_f<P>(v.x) * inv * lo_f<P>(g.x), hi_f<P>(v.x) * inv * hi_f<P>(g.x));
+      o.y = pack2<P>(lo_f<P>(v.y) * inv * lo_f<P>(g.y), hi_f<P>(v.y) * inv * hi_f<P>(g.y));
+      *reinterpret_cast<uint2*>(xn_out + (long)t * N + i) = o;
+    };
+    if (ok0) norm(o0, g0, i0);
+    if (ok1) norm(o1, g1, i1);
+    return;
+  }
+  // S <= 8 (every planned layer GEMM): all partial loads of a pair of column groups are issued before the first add.
+  // The kernel is one block per row and latency bound -- with the loads chained behind the adds a row of 8 splits
+  // cost five dependent round trips per group (7.3 us at N = 8192); now it is one.
+  const bool wide_issue = S <= 8;
   for (int i = threadIdx.x * 4; i < N; i += 1024 * 4) {
-    const f32x4 a = sum_splits(part + (long)t * N + i, S, sstride);
+    f32x4 a;
+    if (wide_issue) {
+      f32x4 v[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        v[s2] = s2 < S ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i + (long)s2 * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+      a = v[0];
+#pragma unroll
+      for (int s2 = 1; s2 < 8; ++s2)
+        if (s2 < S) a += v[s2];                       // fixed order 0..S-1
+    } else {
+      a = sum_splits(part + (long)t * N + i, S, sstride);
+    }
     // GEMM output is rounded to the model dtype before the residual add (F.linear returns dtype)
     float v0 = rnd<P>(a[0]), v1 = rnd<P>(a[1]), v2 = rnd<P>(a[2]), v3 = rnd<P>(a[3]);
     if (residual) {
