@@ -196,9 +196,26 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
   const int h = blockIdx.x, qt = gridDim.y - 1 - blockIdx.y;
   const int g = Hq / Hkv;
   const int nrows = T * g;
+  // First K / V^T tile of this wave: its addresses depend on the block and wave index only, so the loads go out before
+  // the device-resident prefix length is known (one dependent round trip less on a launch that lasts ~3 of them).
+  // Rows past kv_end hold zeros or stale finite values (the cache is zero-initialised) and are masked below.
+  const int k_lo = blockIdx.z * KBK;
+  const int kstart = k_lo + wv * 32;
+  const bool spec = kstart + 32 <= Lmax;
+  u32x4 ka[2][DS], kb2[2][DS], va[DT], vb[DT];
+  if (spec) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const u16* kp = kc + ((long)blockIdx.x * Lmax + kstart + (j >> 2) * 8 + s * 4 + (j & 3)) * D + gq * 8;
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) ka[s][ds] = *reinterpret_cast<const u32x4*>(kp + ds * 32);
+    }
+    const u16* vp = vt + (long)blockIdx.x * D * VT_LD(Lmax) + kstart + gq * 8;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) va[dt] = *reinterpret_cast<const u32x4*>(vp + (long)(dt * 16 + j) * VT_LD(Lmax));
+  }
   const int prefix = *prefix_p;
   const int kv_end = prefix + n_mask_keys;
-  const int k_lo = blockIdx.z * KBK;
   if (k_lo >= kv_end) return;                                  // whole block: span not in use yet
   int k_hi = min(kv_end, k_lo + KBK);
   const u16* kbase = kc + (long)h * Lmax * D;
@@ -309,9 +326,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
     }
   };
 
-  u32x4 ka[2][DS], kb2[2][DS], va[DT], vb[DT];
-  const int kstart = k_lo + wv * 32;
-  if (kstart < k_hi) { load_k(kstart, ka); load_v(kstart, va); }
+  if (kstart < k_hi && !spec) { load_k(kstart, ka); load_v(kstart, va); }
   for (int k0 = kstart; k0 < k_hi; k0 += 2 * NW * 32) {
     const int k1 = k0 + NW * 32;
     const bool two = k1 < k_hi;
