@@ -202,8 +202,22 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
   const bool pr = paired && head < Hq + Hkv;
   for (int d = threadIdx.x; d < half; d += 64) {
     const int ca = pr ? 2 * d : d, cb = pr ? 2 * d + 1 : d + half;
-    float a = base[ca], b = base[cb];
-    for (int s = 1; s < S; ++s) { a += base[s * sstride + ca]; b += base[s * sstride + cb]; }
+    float a, b;
+    if (S <= 8) {                                    // all partial loads in flight before the first add (latency bound)
+      float va[8], vb[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        va[s] = s < S ? base[s * sstride + ca] : 0.f;
+        vb[s] = s < S ? base[s * sstride + cb] : 0.f;
+      }
+      a = va[0]; b = vb[0];
+#pragma unroll
+      for (int s = 1; s < 8; ++s)
+        if (s < S) { a += va[s]; b += vb[s]; }       // fixed order 0..S-1
+    } else {
+      a = base[ca]; b = base[cb];
+      for (int s = 1; s < S; ++s) { a += base[s * sstride + ca]; b += base[s * sstride + cb]; }
+    }
     if (bias) {        // F.linear(x, W, b) (qwen.py:94-96): bias joins the fp32 accumulator, one rounding; HF feature order
       a += P::to_f(bias[head * D + d]); b += P::to_f(bias[head * D + d + half]);
     }
