@@ -74,3 +74,24 @@ def test_linear_plan_is_a_function_of_shape_only():
             lib.umb_gemm_plan(N, K, awq, 0, C.byref(R), C.byref(S))
             assert seen.setdefault((N, K, awq), (R.value, S.value)) == (R.value, S.value)
             assert R.value in (1, 2) and 1 <= S.value <= 16 and (K // 128) // S.value >= (4 if awq else 2)
+
+
+def test_wide_forward_split_rule():
+    """umb_gemm_wide_split: the plan's S up to 64 tokens (batch invariance), beyond that the S <= plan that fills
+    the verify kernel's 512 block slots once -- the measured optima of the 70B layer shapes."""
+    from umbrella_amd import _lib
+    lib = _lib.load()
+    plan = {"qkv": (10240, 7), "o": (8192, 8), "down": (8192, 8), "gu": (57344, 1)}
+    for T in (1, 13, 64):
+        for N, S in plan.values():
+            assert lib.umb_gemm_wide_split(T, N, S) == S
+    want = {257: {"qkv": 6, "o": 8, "down": 8}, 769: {"qkv": 2, "o": 2, "down": 2}, 1024: {"qkv": 3, "o": 2, "down": 2},
+            128: {"qkv": 7, "o": 8, "down": 8}}
+    for T, row in want.items():
+        for name, s in row.items():
+            N, S = plan[name]
+            assert lib.umb_gemm_wide_split(T, N, S) == s, (T, name)
+        assert lib.umb_gemm_wide_split(T, *plan["gu"]) == 1               # SiLU epilogue: never split
+    for T in range(65, 1100, 37):                                          # always within [1, plan]
+        for N, S in plan.values():
+            assert 1 <= lib.umb_gemm_wide_split(T, N, S) <= S
