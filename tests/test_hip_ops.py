@@ -107,6 +107,36 @@ def test_reduce_residual_norm_and_silu(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,N", [(1, 2048), (4, 8192), (8, 8192), (8, 5120), (16, 2048), (13, 4096), (9, 8192), (16, 8192),
+                                 (3, 12288)])
+def test_reduce_residual_norm_paths(dev, dtype, S, N):
+    """Row reduce over every code path: whole row in registers (<= 8 splits x 2 column groups, <= 16 splits x 1 group)
+    and the generic loop; with / without residual and norm; splits summed in order 0..S-1 (bit-exact vs fp32 torch
+    summed the same way)."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(S * 100003 + N)
+    T = 5
+    part = torch.randn(S, T, N, generator=g)
+    res = torch.randn(T, N, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype)
+    acc = part[0].clone()
+    for s in range(1, S):
+        acc += part[s]                                           # the kernel's summation order
+    for with_res, with_norm in ((True, True), (False, True), (True, False)):
+        h = torch.zeros(T, N, dtype=dtype, device=dev)
+        xn = torch.zeros(T, N, dtype=dtype, device=dev)
+        _lib.call("umb_reduce_residual_norm", part.to(dev), S, T, N, res.to(dev) if with_res else None, h,
+                  xn if with_norm else None, w.to(dev) if with_norm else None, 1e-5, _lib.dtype_code(dtype))
+        href = acc.to(dtype)
+        if with_res:
+            href = href + res
+        assert torch.equal(h.cpu(), href), (S, N, with_res)
+        if with_norm:
+            xref = O.rmsnorm(h.cpu(), w, 1e-5)
+            assert (xn.cpu().float() - xref.float()).abs().max() <= 2 * torch.finfo(dtype).eps * xref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_qkv_rope_kv_append(dev, dtype):
     from umbrella_amd import _lib
     g = torch.Generator().manual_seed(2)

@@ -63,28 +63,28 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
   const int t = blockIdx.x;
   const long sstride = (long)T * N;
   float ss = 0.f;
-  if (S <= 8 && N <= 8192) {
-    // Whole row in registers (<= 2 column groups per thread): every load of the kernel -- partials, residual, norm
-    // weight -- is issued before the first add, and the normalised row is produced from registers (no LDS row).
+  const bool deep = N <= 4096;                               // one column group per thread: room for 16 splits
+  if ((S <= 8 && N <= 8192) || (S <= 16 && deep)) {
+    // Whole row in registers (<= 2 column groups per thread, or 1 group of <= 16 splits): every load of the kernel --
+    // partials, residual, norm weight -- is issued before the first add, and the normalised row is produced from
+    // registers (no LDS row).
     const int i0 = threadIdx.x * 4, i1 = i0 + 4096;
     const bool ok0 = i0 < N, ok1 = i1 < N;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 v0[8], v1[8];
+    f32x4 v0[8], v1[8];                                        // deep: v1 = splits 8..15 of group 0
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) {
       v0[s2] = (ok0 && s2 < S) ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i0 + (long)s2 * sstride) : z;
-      v1[s2] = (ok1 && s2 < S) ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i1 + (long)s2 * sstride) : z;
+      const bool use1 = deep ? (ok0 && s2 + 8 < S) : (ok1 && s2 < S);
+      const long off1 = deep ? (long)t * N + i0 + (long)(s2 + 8) * sstride : (long)t * N + i1 + (long)s2 * sstride;
+      v1[s2] = use1 ? *reinterpret_cast<const f32x4*>(part + off1) : z;
     }
     const uint2 z2 = {0u, 0u};
     const uint2 r0 = (residual && ok0) ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i0) : z2;
     const uint2 r1 = (residual && ok1) ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i1) : z2;
     const uint2 g0 = (xn_out && ok0) ? *reinterpret_cast<const uint2*>(w + i0) : z2;
     const uint2 g1 = (xn_out && ok1) ? *reinterpret_cast<const uint2*>(w + i1) : z2;
-    auto finish = [&](const f32x4 (&v)[8], const uint2& r, bool ok, int i) -> uint2 {
-      f32x4 a = v[0];
-#pragma unroll
-      for (int s2 = 1; s2 < 8; ++s2)
-        if (s2 < S) a += v[s2];                                  // fixed order 0..S-1
+    auto finish = [&](f32x4 a, const uint2& r, bool ok, int i) -> uint2 {
       float x0 = rnd<P>(a[0]), x1 = rnd<P>(a[1]), x2 = rnd<P>(a[2]), x3 = rnd<P>(a[3]);
       if (residual) { x0 += lo_f<P>(r.x); x1 += hi_f<P>(r.x); x2 += lo_f<P>(r.y); x3 += hi_f<P>(r.y); }
       uint2 o;
@@ -96,8 +96,21 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
       }
       return o;
     };
-    const uint2 o0 = finish(v0, r0, ok0, i0);
-    const uint2 o1 = finish(v1, r1, ok1, i1);
+    f32x4 a0 = v0[0], a1 = v1[0];
+#pragma unroll
+    for (int s2 = 1; s2 < 8; ++s2)
+      if (s2 < S) a0 += v0[s2];                                  // fixed order 0..S-1
+    if (deep) {
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        if (s2 + 8 < S) a0 += v1[s2];
+    } else {
+#pragma unroll
+      for (int s2 = 1; s2 < 8; ++s2)
+        if (s2 < S) a1 += v1[s2];
+    }
+    const uint2 o0 = finish(a0, r0, ok0, i0);
+    const uint2 o1 = finish(a1, r1, ok1 && !deep, i1);
     if (!xn_out) return;
     ss = block_sum<1024>(ss, red);
     const float inv = rsqrtf(ss / (float)N + eps);
