@@ -30,11 +30,12 @@ def hip_model(cfgd, seed, max_length, dtype, device, awq=False, eos=(3, 5), **kw
 
 
 def static_engine(g, device, dtype, self_draft=True, gm="3x4", max_length=256, safe_buffer=16, awq=False,
-                  eos=(3, 5), hip_graph=True, **kw):
+                  eos=(3, 5), hip_graph=True, draft_exit_layer=None, **kw):
     tcfg, tseed = g["target_cfg"], g["seeds"]["target"]
     dcfg, dseed = (tcfg, tseed) if self_draft else (g["draft_cfg"], g["seeds"]["draft"])
     target, tsd = hip_model(tcfg, tseed, max_length, dtype, device, awq=awq, eos=eos)
-    draft, _ = hip_model(dcfg, dseed, max_length, dtype, device, awq=awq and self_draft, eos=eos, cuda_graph=True)
+    dkw = {"exit_layer": draft_exit_layer} if draft_exit_layer else {}
+    draft, _ = hip_model(dcfg, dseed, max_length, dtype, device, awq=awq and self_draft, eos=eos, cuda_graph=True, **dkw)
     eng = StaticSpeculationEngine("tiny-draft", "tiny-target", dtype=dtype, device=str(device), growmap=growmap(gm),
                                   max_length=max_length, safe_buffer=safe_buffer, stop_distance=8,
                                   draft_model_obj=draft, target_model_obj=target, tokenizer=IdTokenizer(),
@@ -44,12 +45,12 @@ def static_engine(g, device, dtype, self_draft=True, gm="3x4", max_length=256, s
 
 
 def dynamic_engine(g, device, dtype, self_draft=True, width=8, num_beams=8, depth=4, max_length=256, safe_buffer=16,
-                   eos=(3, 5), offload=False, hip_graph=True, num_cache_layers=0, **kw):
+                   eos=(3, 5), offload=False, hip_graph=True, num_cache_layers=0, awq=False, **kw):
     tcfg, tseed = g["target_cfg"], g["seeds"]["target"]
     dcfg, dseed = (tcfg, tseed) if self_draft else (g["draft_cfg"], g["seeds"]["draft"])
     target, tsd = hip_model(tcfg, tseed, max_length, dtype, device, eos=eos, offload=offload,
-                            num_cache_layers=num_cache_layers)
-    draft, _ = hip_model(dcfg, dseed, max_length, dtype, device, eos=eos)
+                            num_cache_layers=num_cache_layers, awq=awq)
+    draft, _ = hip_model(dcfg, dseed, max_length, dtype, device, eos=eos, awq=awq and self_draft)
     eng = DynamicSpeculationEngine("tiny-draft", "tiny-target", dtype=dtype, device=str(device), width=width,
                                    num_beams=num_beams, depth=depth, max_length=max_length, safe_buffer=safe_buffer,
                                    stop_distance=8, draft_model_obj=draft, target_model_obj=target,

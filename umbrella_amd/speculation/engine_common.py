@@ -83,6 +83,12 @@ class HipEngine(BaseEngine):
     def _alloc_state(self, tree_size, max_path):
         dev = self.device
         self.tree_size, self.max_path = tree_size, max_path
+        # one iteration writes KV slots / RoPE positions n .. n + tree_size - 1: the context guard must cover the whole
+        # tree, not only `safe_buffer` (the reference fails with a slice-shape error at the same point; here the kernels
+        # would write past the caches).  guard == safe_buffer whenever the tree fits in it (all static growmaps).
+        self._guard = max(self.safe_buffer, tree_size + 1)
+        assert self.max_length > self.safe_buffer + self._guard, (
+            f"max_length {self.max_length} cannot hold a {tree_size}-node tree plus safe_buffer {self.safe_buffer}")
         self.tokens = torch.zeros(self.max_length + tree_size + 8, dtype=torch.int32, device=dev)
         self.n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sampled = torch.zeros(tree_size, dtype=torch.int32, device=dev)
@@ -136,7 +142,7 @@ class HipEngine(BaseEngine):
     @torch.inference_mode()
     def _prefill(self, input_ids: torch.LongTensor):
         P = input_ids.shape[1]
-        if P >= self.max_length - 2 * self.safe_buffer:
+        if P + self.num_nodes >= self.max_length - self.safe_buffer - self._guard:
             return False
         base = self.num_nodes
         self.tokens[base:base + P] = input_ids[0].to(device=self.device, dtype=torch.int32)
@@ -146,7 +152,7 @@ class HipEngine(BaseEngine):
     @torch.inference_mode()
     def _append(self, input_ids: torch.LongTensor):
         A = input_ids.shape[1]
-        if A + self.num_nodes >= self.max_length - 2 * self.safe_buffer:
+        if A + self.num_nodes >= self.max_length - self.safe_buffer - self._guard:
             return False
         n = self.num_nodes
         self.tokens[n + 1:n + 1 + A] = input_ids[0].to(device=self.device, dtype=torch.int32)
@@ -222,6 +228,9 @@ class HipEngine(BaseEngine):
     @torch.inference_mode()
     def step(self) -> bool:
         """build_tree + verify as one launch; returns continue_generation."""
+        if self.num_nodes + self.tree_size > self.max_length:
+            raise RuntimeError(f"speculation tree of {self.tree_size} nodes at position {self.num_nodes} exceeds "
+                               f"max_length {self.max_length}: check validate_status() before step()")
         if getattr(self, "enable_override", False):
             self._fill_override()
         if self.use_graph:
@@ -250,7 +259,7 @@ class HipEngine(BaseEngine):
 
     # ------------------------------------------------------------------ generation loops
     def validate_status(self):
-        return self.num_nodes <= (self.max_length - self.safe_buffer)
+        return self.num_nodes <= (self.max_length - self._guard)
 
     def update_generation_args(self, **generation_args):
         before = (self.temperature, self.topp, self.repetition_penalty, self.topk)
