@@ -78,6 +78,37 @@ typedef struct UmbGemmFused {
 int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
                    int awq, int S, int R, int epi, const UmbGemmFused* fx, int dtype, umb_stream_t stream);
 
+/* ------------------------------------------------------------------ low-latency layer GEMMs (T <= 64 tokens)
+ * One workgroup owns its output rows for the whole K (in-block K split, summed through LDS in slice order), so the
+ * epilogue -- residual add, RMSNorm bookkeeping, SiLU * up, RoPE + KV append -- runs in the GEMM launch: 5 launches per
+ * decoder layer, no fp32 partial round trips (csrc/lowlat.hip).  Activations are exchanged in "FM" layout = MFMA
+ * B-fragment order [K/32][TT][64 lanes][8 x 16-bit], TT = umb_ll_token_tiles(T) token tiles of 16: element (t, k) at
+ *   ((((k/32) * TT + t/16) * 64 + (k%32/8) * 16 + t%16) * 8 + k%8.
+ * Replaces the same reference lines as umb_gemm_fused; AWQ int4 uses the folded form s * sum_k (q - z) x in fp32
+ * (no fp16 rounding of (q - z) * s).  epi: 0 fp32 out[T - row_from][N] (* 1/rms, rounded to dtype if round_out);
+ * 2 SiLU(gate) * up -> out = act in FM layout (K' = N/2); 3 q/k/v + RoPE + KV append; 4 residual. */
+typedef struct UmbGemmLL {
+  int32_t row_from, round_out;                 /* epi 0 */
+  const float* ssq_in; int32_t ssq_groups, ssq_in_stride; float ssq_dim, eps;   /* 1/rms of the producer's stream; NULL: 1 */
+  void* h; void* hw; const void* norm_w; float* ssq_out; int32_t ssq_out_stride, pad0;   /* epi 4: h row-major, hw FM */
+  const int32_t* pos; const int32_t* slot; const void* cosT; const void* sinT;             /* epi 3 */
+  void* q_out; void* k_cache; void* vt_cache; const void* bias; int32_t Hq, Hkv, D, Lmax;
+} UmbGemmLL;
+int umb_gemm_ll(void* out, const void* x_fm, const void* wpacked, const void* meta, int T, int N, int K, int awq,
+                int epi, const UmbGemmLL* fx, int dtype, umb_stream_t stream);
+/* (R n-tiles per wave, WN row groups x WK K-slices = NW waves per block) for a [N][K] linear: shape-only, so a
+ * token's result never depends on its batch mates; epi 4 writes N / 16 / R sums of squares per token. */
+void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int* WK_out, int* NW_out);
+int umb_ll_token_tiles(int T);                  /* 1, 2 or 4 for T = 1..64; 0 otherwise */
+int umb_to_fm(void* out_fm, const void* x, int T, int K, int dtype, umb_stream_t stream);      /* row-major -> FM */
+int umb_from_fm(void* out, const void* x_fm, int T, int K, int dtype, umb_stream_t stream);
+/* umb_embed_prep for the low-latency schedule: h row-major, hw = h * norm_w in FM layout, ssq[t][0..4); tokens /
+ * positions / slots are clamped into [0, V) / [0, Lmax) (a tree that overruns the context cannot write past the caches) */
+int umb_embed_ll(void* h, const void* table, int H, int V, int Lmax, int T, const int* tok, const int* pos,
+                 const int* slot, const int* prefix, const int* tokens_all, const int* n_ptr, int off,
+                 const int* depth, int* pos_out, int* slot_out, int* prefix_out, void* hw_fm, const void* norm_w,
+                 float* ssq, int ssq_stride, int dtype, umb_stream_t stream);
+
 /* ------------------------------------------------------------------ stand-alone epilogues (op-level API) */
 /* flashinfer.rmsnorm (umbrella/models/model_utils.py:54-64) */
 int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype, umb_stream_t stream);
@@ -118,6 +149,13 @@ int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_
                   const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T, int Hq,
                   int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, uint32_t* counters, int dtype,
                   umb_stream_t stream);
+
+/* the same, output optionally in FM layout (out_fm_tt = umb_ll_token_tiles(T); 0 = row-major [T][Hq][D]); FM output
+ * needs the single-launch path (counters != NULL or Lmax <= 2048) */
+int umb_tree_attn2(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
+                   const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T, int Hq,
+                   int Hkv, int D, int Lmax, int chunk, int max_splits, float scale, uint32_t* counters, int out_fm_tt,
+                   int dtype, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ tree bookkeeping */
 /* target_logits.argmax(-1) (static_speculation_engine.py:307) */
@@ -200,8 +238,9 @@ typedef struct UmbWorkspace {
   uint32_t* counters;               /* >= max(N)/64 zeroed words for the split-K last-arriver epilogues */
   uint32_t* attn_counters;          /* >= Hkv * ceil(Tmax*(Hq/Hkv)/16) zeroed words */
   int32_t Tmax, attn_chunk, attn_splits, ssq_stride;
-  int32_t fused, pad_;              /* layer schedule: 0 = 9 launches (split-K reduced at kernel boundaries, fastest
-                                       measured on MI355X), 1 = 5 launches (in-kernel last-arriver reduces) */
+  int32_t fused, pad_;              /* layer schedule: 0 = 8 launches (split-K reduced at kernel boundaries), 1 = 5 launches
+                                       (in-kernel last-arriver reduces; slower), 2 = low-latency 5 launches (whole-K
+                                       workgroups, FM activations; T <= 64 only, wider forwards use schedule 0) */
 } UmbWorkspace;
 
 typedef struct UmbStep {

@@ -1,0 +1,144 @@
+"""A/B micro-benchmark: split-K family (umb_gemm + its reduce kernel) vs low-latency family (umb_gemm_ll) per layer
+shape, weights rotated over enough copies that every launch streams from HBM; then whole forwards of a model under
+hipGraph replay with both schedules (UMB_SCHED).  Usage: python scripts/ll_bench.py [1b] [70b] [8b] [fwd1b] [fwd70b]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+ge.build()
+from umbrella_amd import _lib
+from umbrella_amd.models.llama import PackedLinear, ll_plan, to_fm
+from umbrella_amd.models.synthetic import synth_awq_tensors
+
+dev = "cuda:0"
+gen = torch.Generator(device=dev).manual_seed(0)
+SHAPES = {"70b": (torch.float16, 13, [("qkv", 10240, 8192, 1, 0), ("o", 8192, 8192, 1, 0), ("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 1, 0)]),
+          "1b": (torch.float16, 3, [("qkv", 3072, 2048, 0, 0), ("o", 2048, 2048, 0, 0), ("gu", 16384, 2048, 0, 1), ("down", 2048, 8192, 0, 0),
+                                    ("head", 128256, 2048, 0, 0)]),
+          "8b": (torch.bfloat16, 31, [("qkv", 6144, 4096, 0, 0), ("o", 4096, 4096, 0, 0), ("gu", 28672, 4096, 0, 1), ("down", 4096, 14336, 0, 0)])}
+
+
+def timeit(fn, reps=40, warm=4):
+    for i in range(warm):
+        fn(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(reps):
+        fn(i + warm)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def bench_shapes(model):
+    dtype, T, shapes = SHAPES[model]
+    T = int(os.environ.get("T", T))
+    dt = _lib.dtype_code(dtype)
+    tot = [0.0, 0.0, 0.0]
+    for name, N, K, awq, il in shapes:
+        per = N * K // 2 + (N // 16) * (K // 128) * 64 if awq else N * K * 2
+        ncopy = max(2, int(700e6 // per) + 1)
+        lins = []
+        for _ in range(ncopy):
+            if awq:
+                lins.append(PackedLinear.from_awq(*synth_awq_tensors(N, K, 128, dev, gen), interleave=bool(il)))
+            else:
+                lins.append(PackedLinear.from_dense(torch.randn(N, K, device=dev, dtype=dtype) * 0.02, interleave=bool(il),
+                                                    force_s1=(name == "head")))
+        ln = lins[0]
+        x = torch.randn(T, K, device=dev).to(dtype)
+        xfm = to_fm(x)
+        part = torch.empty(max(ln.S * T * N, 1), dtype=torch.float32, device=dev)
+        h = torch.zeros(T, N, dtype=dtype, device=dev)
+        xn = torch.zeros(T, N, dtype=dtype, device=dev)
+        nw = torch.ones(N, dtype=dtype, device=dev)
+        epi_old = 2 if il else (1 if name == "head" else 0)
+        S_eff = ln.S
+        if name in ("o", "down") and T <= 64:           # what model.hip's eff_s() does for the row-reduced GEMMs
+            cap = max(K // 1792, 4)
+            if ln.S > cap and (N // (64 * ln.R)) * cap >= 256:
+                S_eff = cap
+
+        def old(i):
+            l = lins[i % ncopy]
+            _lib.call("umb_gemm", part, x, K, l.w, l.meta, T, N, K, l.awq, S_eff if epi_old == 0 else l.S, l.R, epi_old, dt)
+            if name in ("o", "down"):
+                _lib.call("umb_reduce_residual_norm", part, S_eff, T, N, h, h, xn, nw, 1e-5, dt)
+
+        # low-latency: the layer's own epilogue (logits for head / qkv, SiLU for gate-up, residual for o / down)
+        fx = _lib.UmbGemmLL()
+        out_ll = torch.empty(T * N, dtype=torch.float32, device=dev)
+        R, WN, WK, NW = ll_plan(N, K, bool(awq))
+        ssq = torch.zeros(T, max(N // 16, 4), dtype=torch.float32, device=dev)
+        hw = torch.zeros(64 * N, dtype=dtype, device=dev)
+        epi_new = 2 if il else (4 if name in ("o", "down") else 0)
+        if epi_new == 4:
+            fx.h, fx.hw, fx.norm_w, fx.ssq_out, fx.ssq_out_stride = h.data_ptr(), hw.data_ptr(), nw.data_ptr(), ssq.data_ptr(), ssq.shape[1]
+
+        def new(i):
+            l = lins[i % ncopy]
+            _lib.call("umb_gemm_ll", out_ll, xfm, l.w, l.meta, T, N, K, l.awq, epi_new, fx, dt)
+        us_old, us_new = timeit(old), timeit(new)
+        tot[0] += per; tot[1] += us_old; tot[2] += us_new
+        print(f"{model} {name:5s} N={N:6d} K={K:5d} awq={awq} T={T}: split S={S_eff} {us_old:7.2f} us {per/us_old/1e3:6.0f} GB/s | "
+              f"ll R={R} WN={WN} WK={WK} {us_new:7.2f} us {per/us_new/1e3:6.0f} GB/s", flush=True)
+        del lins
+        torch.cuda.empty_cache()
+    print(f"{model} layer GEMMs: split {tot[1]:.1f} us ({tot[0]/tot[1]/1e3:.0f} GB/s) | ll {tot[2]:.1f} us ({tot[0]/tot[2]/1e3:.0f} GB/s)", flush=True)
+
+
+def bench_forward(name, layers, T, dtype):
+    """graph-replayed T-row tree forward of a (possibly truncated) model, both schedules"""
+    import copy
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.models.llama import Llama
+    res = {}
+    for sched in ("split", "ll"):
+        os.environ["UMB_SCHED"] = sched
+        cfg = copy.copy(KNOWN[name])
+        cfg.num_hidden_layers = layers
+        m = Llama(name, max_length=2048, device=dev, dtype=dtype, config=cfg)
+        m.alloc()
+        ids = torch.randint(3, 128000, (128 + T,), dtype=torch.int32, device=dev)
+        m.prefill_tokens(ids[:128], 0)
+        step = ids[128:].contiguous()
+        pos = torch.arange(128, 128 + T, dtype=torch.int32, device=dev)
+        pre = torch.tensor([128], dtype=torch.int32, device=dev)
+        run = lambda: m.forward_explicit(step, pos, pos, pre, head_from=0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 50
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        res[sched] = (time.time() - t0) / n * 1e3
+        wb = m.weight_bytes()
+        del m, g
+        torch.cuda.empty_cache()
+    print(f"forward {name} L={layers} T={T}: split {res['split']:.3f} ms | ll {res['ll']:.3f} ms | weights {wb/1e9:.2f} GB "
+          f"-> {wb/res['ll']/1e6:.0f} GB/s (ll)", flush=True)
+
+
+for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
+    if what in SHAPES:
+        bench_shapes(what)
+    elif what == "fwd1b":
+        for T in (1, 3):
+            bench_forward("meta-llama/Llama-3.2-1B-Instruct", 16, T, torch.float16)
+    elif what == "fwd70b":
+        bench_forward("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", 16, 13, torch.float16)
+    elif what == "fwd8b":
+        bench_forward("meta-llama/Llama-3.1-8B-Instruct", 32, 31, torch.bfloat16)

@@ -38,6 +38,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 40 + 6 * 8
     assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
     assert C.sizeof(_lib.UmbGemmFused) == 144
+    assert C.sizeof(_lib.UmbGemmLL) == 152
     assert C.sizeof(_lib.UmbStep) == 8 + 8 * 8 + 6 * 4
     assert C.sizeof(_lib.UmbOffload) == 8 + 8 + 16 + 8 + 16 + 16
 
@@ -50,6 +51,23 @@ def test_gemm_plan_is_token_count_free(lib):
         assert (N // 16) % R.value == 0 and 1 <= S.value <= 16 and (K // 128) >= S.value
         lib.umb_gemm_plan(N, K, awq, 1, C.byref(R), C.byref(S))
         assert S.value == 1
+
+
+def test_ll_plan_is_shape_only_and_consistent(lib):
+    """Low-latency GEMM plan (csrc/lowlat.hip): R n-tiles per wave, WN x WK = 8 waves, K-slices of equal length."""
+    import ctypes as C
+    shapes = [(3072, 2048, 0), (2048, 2048, 0), (16384, 2048, 0), (2048, 8192, 0), (128256, 2048, 0), (6144, 4096, 0),
+              (28672, 4096, 1), (4096, 14336, 1), (10240, 8192, 1), (8192, 8192, 1), (57344, 8192, 1), (8192, 28672, 1),
+              (384, 256, 0), (256, 128, 0), (512, 256, 1)]
+    for (N, K, awq) in shapes:
+        v = [C.c_int() for _ in range(4)]
+        lib.umb_ll_plan(N, K, awq, *[C.byref(x) for x in v])
+        R, WN, WK, NW = (x.value for x in v)
+        assert NW == 8 and WN * WK == NW and R in (1, 2)
+        assert (N // 16) % R == 0 and (K // 128) % WK == 0
+        if awq and R == 2:
+            assert (N // 16) % 2 == 0
+    assert [lib.umb_ll_token_tiles(t) for t in (0, 1, 16, 17, 32, 33, 48, 49, 64, 65)] == [0, 1, 1, 2, 2, 4, 4, 4, 4, 0]
 
 
 def test_missing_library_fails_loudly(monkeypatch):

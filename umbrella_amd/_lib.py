@@ -61,6 +61,15 @@ class UmbGemmFused(C.Structure):
                 ("Hkv", C.c_int32), ("D", C.c_int32), ("Lmax", C.c_int32)]
 
 
+class UmbGemmLL(C.Structure):
+    _fields_ = [("row_from", C.c_int32), ("round_out", C.c_int32), ("ssq_in", C.c_void_p), ("ssq_groups", C.c_int32),
+                ("ssq_in_stride", C.c_int32), ("ssq_dim", C.c_float), ("eps", C.c_float), ("h", C.c_void_p),
+                ("hw", C.c_void_p), ("norm_w", C.c_void_p), ("ssq_out", C.c_void_p), ("ssq_out_stride", C.c_int32),
+                ("pad0", C.c_int32), ("pos", C.c_void_p), ("slot", C.c_void_p), ("cosT", C.c_void_p),
+                ("sinT", C.c_void_p), ("q_out", C.c_void_p), ("k_cache", C.c_void_p), ("vt_cache", C.c_void_p),
+                ("bias", C.c_void_p), ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32), ("Lmax", C.c_int32)]
+
+
 class UmbStep(C.Structure):
     _fields_ = [("T", C.c_int32), ("tree_off", C.c_int32), ("tokens", C.c_void_p), ("positions", C.c_void_p),
                 ("slots", C.c_void_p), ("prefix_len", C.c_void_p), ("tokens_all", C.c_void_p),
@@ -83,6 +92,13 @@ SIGNATURES = {
     "umb_gemm_wide_split": [_I, _I, _I],
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_fused": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(UmbGemmFused), _I, _P],
+    "umb_gemm_ll": [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(UmbGemmLL), _I, _P],
+    "umb_ll_plan": [_I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
+    "umb_ll_token_tiles": [_I],
+    "umb_to_fm": [_P, _P, _I, _I, _I, _P],
+    "umb_from_fm": [_P, _P, _I, _I, _I, _P],
+    "umb_embed_ll": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "umb_tree_attn2": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],
     "umb_reduce_residual_norm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P],
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
@@ -106,7 +122,7 @@ SIGNATURES = {
     "umb_bench_launch": [_I, _I, _P, _P],
     "umb_version": [],
 }
-_VOID = {"umb_gemm_plan"}
+_VOID = {"umb_gemm_plan", "umb_ll_plan"}
 _STR = {"umb_version"}
 
 _lib = None

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
                                                          int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
                                                          int Lmax, float scale, u16* __restrict__ out, int KBK,
                                                          float* __restrict__ po, float* __restrict__ pml,
-                                                         unsigned* __restrict__ counters) {
+                                                         unsigned* __restrict__ counters, int out_fm_tt) {
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ f32x4 so[NW][DT][64];
   __shared__ float sm[NW][16], sl[NW][16];
@@ -364,7 +364,14 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
   auto store_out = [&](const f32x4& a, float inv, int dt) {
     uint2 o2;
     o2.x = pack2<P>(a[0] * inv, a[1] * inv); o2.y = pack2<P>(a[2] * inv, a[3] * inv);
-    *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
+    if (out_fm_tt) {
+      // FM layout (MFMA B-fragment order of the o-projection, csrc/lowlat.hip): element (t, f = hq * D + d)
+      const int f = hq * D + dt * 16 + gq * 4;
+      const long off = ((((long)(f >> 5) * out_fm_tt + (t >> 4)) * 64 + ((f >> 3) & 3) * 16 + (t & 15)) << 3) + (f & 7);
+      *reinterpret_cast<uint2*>(out + off) = o2;
+    } else {
+      *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
+    }
   };
   if (nsp == 1) {
     if (row_ok) {
@@ -467,11 +474,12 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(u16* __restrict__ out
 // partial buffers: po  [max_splits][T][Hq][D] fp32, pml [max_splits][T][Hq][2] fp32
 // counters: >= Hkv * ceil(T * (Hq/Hkv) / 16) zeroed uint32 (self-resetting) -> single-launch kernel for any Lmax;
 // NULL -> single launch only if Lmax <= 2048, else key splits + a combine kernel
-extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
-                             const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
-                             int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
-                             unsigned* counters, int dtype, hipStream_t st) {
+extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
+                              const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
+                              int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
+                              unsigned* counters, int out_fm_tt, int dtype, hipStream_t st) {
   if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 8 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
+  if (out_fm_tt && (out_fm_tt * 16 < T || (Hq * D) % 32)) return UMB_EINVAL;
   const int nrows = T * (Hq / Hkv);
   const int nqt = (nrows + 15) / 16;
   // Single-launch kernel: with a counters buffer for any Lmax (spans of 2048 keys, cross-block merge only once the
@@ -491,7 +499,7 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
 #define ATT1N_(DD, NWV)                                                                                           \
   hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,    \
                      (const u16*)vt_cache, prefix_len, (const unsigned long long*)mask_bits, mask_words,           \
-                     n_mask_keys, T, Hq, Hkv, Lmax, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters)
+                     n_mask_keys, T, Hq, Hkv, Lmax, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt)
 #define ATT1_(DD)                                                                                                 \
   if (nw == 1) { ATT1N_(DD, 1); } else if (nw == 2) { ATT1N_(DD, 2); } else if (nw == 4) { ATT1N_(DD, 4); }       \
   else { ATT1N_(DD, 8); }
@@ -505,6 +513,7 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
     UMB_LAUNCH_CHECK();
     return UMB_OK;
   }
+  if (out_fm_tt) return UMB_EINVAL;             // FM output: single-launch kernel only
   int qpw = 1;
   while ((nqt + 4 * qpw - 1) / (4 * qpw) > 64 && qpw < 8) qpw *= 2;
   const int gz = (nqt + 4 * qpw - 1) / (4 * qpw);
@@ -525,4 +534,12 @@ extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, cons
 #undef ATT_
   UMB_LAUNCH_CHECK();
   return UMB_OK;
+}
+
+extern "C" int umb_tree_attn(void* out, const void* q, const void* k_cache, const void* vt_cache, void* po, void* pml,
+                             const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
+                             int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
+                             unsigned* counters, int dtype, hipStream_t st) {
+  return umb_tree_attn2(out, q, k_cache, vt_cache, po, pml, prefix_len, mask_bits, mask_words, n_mask_keys, T, Hq, Hkv, D,
+                        Lmax, chunk, max_splits, scale, counters, 0, dtype, st);
 }

@@ -35,7 +35,7 @@ static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int
 // embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h
 static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
   if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
-  if (!ws->fused) {
+  if (ws->fused != 1) {
     CK(umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
                       s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
                       nullptr, nullptr, nullptr, 0, m->dtype, st));
@@ -109,15 +109,77 @@ static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   return UMB_OK;
 }
 
+// Schedule 2 (low latency, T <= 64): 5 launches per layer, no cross-workgroup step at all.  Every GEMM workgroup owns
+// its output rows for the whole K (csrc/lowlat.hip) and runs the layer's elementwise work as its epilogue;
+// activations travel in FM (MFMA B-fragment) layout: ws->hw (K = H), ws->attn (K = Hq D), ws->act (K = I).
+static inline bool use_ll(const UmbWorkspace* ws, const UmbStep* s) { return ws->fused == 2 && s->T <= 64; }
+static inline int ll_groups(const UmbLinear& l) {
+  int R, WN, WK, NW;
+  umb_ll_plan(l.N, l.K, l.awq, &R, &WN, &WK, &NW);
+  return l.N / 16 / R;
+}
+
+static int prologue_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
+  if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
+  return umb_embed_ll(ws->h, s->skip_embed ? nullptr : m->embed, m->H, m->V, m->Lmax, s->T, s->tokens, s->positions,
+                      s->slots, s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot,
+                      ws->prefix, ws->hw, first_norm, ws->ssq, ws->ssq_stride, m->dtype, st);
+}
+
+// ssq_groups: how many partial sums of squares the producer of ws->hw left per token (4 after the embedding kernel,
+// N / 16 / R after a residual GEMM)
+static int layer_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                    const void* next_norm, int* ssq_groups, hipStream_t st) {
+  const int T = s->T, dt = m->dtype;
+  const size_t esz = 2;
+  char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
+  const int og = ll_groups(ly.o), dg = ll_groups(ly.down);
+  if (og > ws->ssq_stride || dg > ws->ssq_stride) return UMB_EINVAL;
+  // 1. qkv: 1/rms, (+bias), RoPE at the tree positions, q out, K / V appended at their slots
+  UmbGemmLL fq = {};
+  fq.ssq_in = ws->ssq; fq.ssq_groups = *ssq_groups; fq.ssq_in_stride = ws->ssq_stride; fq.ssq_dim = (float)m->H; fq.eps = m->eps;
+  fq.pos = ws->pos; fq.slot = ws->slot; fq.cosT = m->rope_cos; fq.sinT = m->rope_sin; fq.q_out = ws->q; fq.k_cache = kc;
+  fq.vt_cache = vt; fq.bias = ly.qkv_bias; fq.Hq = m->Hq; fq.Hkv = m->Hkv; fq.D = m->D; fq.Lmax = m->Lmax;
+  CK(umb_gemm_ll(nullptr, ws->hw, ly.qkv.w, ly.qkv.meta, T, ly.qkv.N, ly.qkv.K, ly.qkv.awq, 3, &fq, dt, st));
+  // 2. tree attention, output in FM layout for the o-projection
+  CK(umb_tree_attn2(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                    ws->attn_counters, umb_ll_token_tiles(T), dt, st));
+  // 3. o_proj: h += o ; hw = h * norm2_w ; sums of squares
+  UmbGemmLL fo = {};
+  fo.h = ws->h; fo.hw = ws->hw; fo.norm_w = ly.norm2; fo.ssq_out = ws->ssq; fo.ssq_out_stride = ws->ssq_stride;
+  CK(umb_gemm_ll(nullptr, ws->attn, ly.o.w, ly.o.meta, T, ly.o.N, ly.o.K, ly.o.awq, 4, &fo, dt, st));
+  // 4. gate/up (rows interleaved at load): act = SiLU(gate / rms) * up / rms, FM layout
+  UmbGemmLL fg = {};
+  fg.ssq_in = ws->ssq; fg.ssq_groups = og; fg.ssq_in_stride = ws->ssq_stride; fg.ssq_dim = (float)m->H; fg.eps = m->eps;
+  CK(umb_gemm_ll(ws->act, ws->hw, ly.gu.w, ly.gu.meta, T, ly.gu.N, ly.gu.K, ly.gu.awq, 2, &fg, dt, st));
+  // 5. down: h += d ; hw = h * (next layer's norm1 | final norm) ; sums of squares
+  UmbGemmLL fd = {};
+  fd.h = ws->h; fd.hw = ws->hw; fd.norm_w = next_norm; fd.ssq_out = ws->ssq; fd.ssq_out_stride = ws->ssq_stride;
+  CK(umb_gemm_ll(nullptr, ws->act, ly.down.w, ly.down.meta, T, ly.down.N, ly.down.K, ly.down.awq, 4, &fd, dt, st));
+  *ssq_groups = dg;
+  return UMB_OK;
+}
+
+static int head_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int ssq_groups, hipStream_t st) {
+  if (s->head_from >= s->T) return UMB_OK;
+  UmbGemmLL fh = {};
+  fh.row_from = s->head_from; fh.round_out = 1;
+  fh.ssq_in = ws->ssq; fh.ssq_groups = ssq_groups; fh.ssq_in_stride = ws->ssq_stride; fh.ssq_dim = (float)m->H; fh.eps = m->eps;
+  return umb_gemm_ll(ws->logits, ws->hw, m->lm_head.w, m->lm_head.meta, s->T, m->lm_head.N, m->lm_head.K, m->lm_head.awq,
+                     0, &fh, m->dtype, st);
+}
+
 static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
                  const void* next_norm, hipStream_t st) {
-  return ws->fused ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st);
+  return ws->fused == 1 ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st);
 }
 
 static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
   if (s->head_from >= s->T) return UMB_OK;
   const int rows = s->T - s->head_from;
-  if (!ws->fused) {
+  if (ws->fused != 1) {
     const char* xn = (const char*)ws->xn + (size_t)s->head_from * m->H * 2;
     return lin(m->lm_head, xn, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, nullptr);
   }
@@ -131,12 +193,14 @@ static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hip
 extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
   const int lb = s->layer_begin, le = s->layer_end;
   if (lb < 0 || le > m->L || lb >= le) return UMB_EINVAL;
-  CK(prologue(m, ws, s, m->layers[lb].norm1, st));
+  const bool ll = use_ll(ws, s);
+  int sg = 4;
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st));
   for (int l = lb; l < le; ++l) {
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(layer(m, ws, s, m->layers[l], l, nn, st));
+    CK(ll ? layer_ll(m, ws, s, m->layers[l], l, nn, &sg, st) : layer(m, ws, s, m->layers[l], l, nn, st));
   }
-  if (le == m->L) CK(head(m, ws, s, st));
+  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
 }
 
@@ -175,7 +239,9 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
   advance();
   for (int i = 0; i < 2 && next < le; ++i) { CK(issue_copy(next, issued & 1)); ++issued; ++next; advance(); }
 
-  CK(prologue(m, ws, s, m->layers[lb].norm1, st));
+  const bool ll = use_ll(ws, s);
+  int sg = 4;
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st));
   for (int l = lb; l < le; ++l) {
     UmbLayer cur = m->layers[l];
     int buf = -1;
@@ -185,14 +251,14 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       cur = rebase(m->layers[l], off->dev_slab[buf]);
     }
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(layer(m, ws, s, cur, l, nn, st));
+    CK(ll ? layer_ll(m, ws, s, cur, l, nn, &sg, st) : layer(m, ws, s, cur, l, nn, st));
     if (buf >= 0) {
       ++used;
       if (hipEventRecord((hipEvent_t)off->ev_free[buf], st) != hipSuccess) return UMB_EHIP;
       if (next < le) { CK(issue_copy(next, buf)); ++issued; ++next; advance(); }
     }
   }
-  if (le == m->L) CK(head(m, ws, s, st));
+  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
 }
 

@@ -95,6 +95,18 @@ class PackedLinear:
                   _lib.dtype_code(x.dtype))
         return act
 
+    def apply_ll(self, x: torch.Tensor, round_out=False, fx=None, epi=0, out=None):
+        """Low-latency path (T <= 64): x [T, K] 16-bit row-major -> fp32 [T, N] (epi 0), whole-K workgroups."""
+        T = x.shape[0]
+        if out is None and epi == 0:
+            out = torch.empty(T, self.N, dtype=torch.float32, device=x.device)
+        if fx is None:
+            fx = _lib.UmbGemmLL()
+        fx.round_out = int(round_out)
+        _lib.call("umb_gemm_ll", out, to_fm(x), self.w, self.meta, T, self.N, self.K, self.awq, epi, fx,
+                  _lib.dtype_code(x.dtype))
+        return out
+
     def apply(self, x: torch.Tensor, round_out=False) -> torch.Tensor:
         """x [T, K] 16-bit -> fp32 [T, N] (split-K partials summed in split order)."""
         T = x.shape[0]
@@ -105,6 +117,28 @@ class PackedLinear:
         for s in range(1, self.S):
             out = out + part[s]
         return out
+
+
+def to_fm(x: torch.Tensor) -> torch.Tensor:
+    """row-major [T, K] 16-bit -> FM layout (MFMA B-fragment order, csrc/lowlat.hip); T <= 64, K % 32 == 0."""
+    T, K = x.shape
+    tt = _lib.load().umb_ll_token_tiles(T)
+    out = torch.zeros(tt * 16 * K, dtype=x.dtype, device=x.device)
+    _lib.call("umb_to_fm", out, x.contiguous(), T, K, _lib.dtype_code(x.dtype))
+    return out
+
+
+def from_fm(x_fm: torch.Tensor, T: int, K: int) -> torch.Tensor:
+    out = torch.empty(T, K, dtype=x_fm.dtype, device=x_fm.device)
+    _lib.call("umb_from_fm", out, x_fm, T, K, _lib.dtype_code(x_fm.dtype))
+    return out
+
+
+def ll_plan(N: int, K: int, awq: bool):
+    """(R, WN, WK, NW) of the low-latency GEMM for a [N, K] linear (shape-only)."""
+    vals = [C.c_int(0) for _ in range(4)]
+    _lib.load().umb_ll_plan(N, K, int(awq), *[C.byref(v) for v in vals])
+    return tuple(v.value for v in vals)
 
 
 def pack_mask_bits(mask: torch.Tensor) -> torch.Tensor:
@@ -135,6 +169,9 @@ class Llama(LLMBase):
         # layer schedule: False = 8 launches / layer with kernel-boundary split-K reduces (fastest measured),
         # True = 5 launches / layer with in-kernel last-arriver reduces (see csrc/model.hip)
         self.fused = os.environ.get("UMB_FUSED", "0") == "1"
+        # sched "ll": low-latency schedule for forwards of <= 64 rows -- 5 launches / layer, whole-K workgroups with the
+        # layer's elementwise work as GEMM epilogues, activations in MFMA fragment order (csrc/lowlat.hip)
+        self.sched = os.environ.get("UMB_SCHED", "ll")
         if config is not None:
             self.config = config
         elif os.path.isdir(model_name):
@@ -146,7 +183,7 @@ class Llama(LLMBase):
                              "or a local directory with config.json")
         c = self.config
         if c.attention_bias:
-            self.fused = False                    # projection bias lives in the default schedule's reduce kernel
+            self.fused = False                    # projection bias: default / low-latency schedules only
         self.hidden_size, self.num_heads, self.head_dim = c.hidden_size, c.num_attention_heads, c.head_dim
         self.num_key_value_heads = c.num_key_value_heads
         self.eos_tokens = list(c.eos_token_id)
@@ -224,7 +261,7 @@ class Llama(LLMBase):
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
             lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
-        if self.fused:
+        if self.fused and self.sched != "ll":
             lin.R = 1                              # the in-kernel split epilogues own one n-tile per wave
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
@@ -351,6 +388,7 @@ class Llama(LLMBase):
             return
         tokens, logit_rows = max(tokens, self.ws_tokens), max(logit_rows, self.logit_rows)
         c, dev, dt = self.config, self.device, self.dtype
+        tokens = (tokens + 15) // 16 * 16           # fragment-order activations come in 16-row tiles
         T = tokens
         self.logit_rows = logit_rows
         H, I, QD, V = c.hidden_size, c.intermediate_size, c.q_dim, c.vocab_size
@@ -373,7 +411,7 @@ class Llama(LLMBase):
         w["logits"] = torch.empty(logit_rows if self.is_last else 1, V if self.is_last else 8, dtype=torch.float32,
                                   device=dev)
         w["hw"] = torch.zeros(T, H, dtype=dt, device=dev)
-        self.ssq_stride = (H // 64 + 3) // 4 * 4
+        self.ssq_stride = max(H // 16, 4)           # low-latency schedule: one sum of squares per 16-column tile
         w["ssq"] = torch.zeros(T, self.ssq_stride, dtype=torch.float32, device=dev)
         maxn = max(N for (N, K, S) in self._plans.values())
         if not hasattr(self, "_counters"):          # self-resetting arrival counters (zero between launches)
@@ -388,7 +426,7 @@ class Llama(LLMBase):
         ws.hw, ws.ssq = w["hw"].data_ptr(), w["ssq"].data_ptr()
         ws.counters, ws.attn_counters = self._counters.data_ptr(), self._attn_counters.data_ptr()
         ws.Tmax, ws.attn_chunk, ws.attn_splits, ws.ssq_stride = T, self.attn_chunk, self.attn_splits, self.ssq_stride
-        ws.fused = int(self.fused)
+        ws.fused = 2 if (self.sched == "ll" and not self.fused) else int(self.fused)
 
     @property
     def logits_buffer(self) -> torch.Tensor:
