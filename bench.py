@@ -27,6 +27,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 import sys
 import time
 

@@ -69,9 +69,11 @@ int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void*
  *          K/V appended at slot[t] (attn/cache.py:53-65)
  *   epi 4: h <- round(round(gemm) + h); hw <- h * norm_w (optional); ssq_out[t][n/64] <- sum h^2 (llama.py:104,112) */
 typedef struct UmbGemmFused {
-  const float* ssq_in; int32_t ssq_groups; float ssq_dim; float eps; int32_t pad0;
+  const float* ssq_in; int32_t ssq_groups; float ssq_dim; float eps;
+  int32_t pad0;                     /* row stride of ssq_in in floats (0: ssq_groups) */
   uint32_t* counters;               /* >= N/64 zeroed words, self-resetting */
-  void* h; void* hw; const void* norm_w; float* ssq_out; int32_t ssq_out_stride; int32_t pad1;
+  void* h; void* hw; const void* norm_w; float* ssq_out; int32_t ssq_out_stride;
+  int32_t pad1;                     /* bit 0: x is in FM layout (T <= 64); bit 1: the epi-2 output is written in FM layout */
   const int32_t* pos; const int32_t* slot; const void* cosT; const void* sinT;
   void* q_out; void* k_cache; void* vt_cache; int32_t Hq, Hkv, D, Lmax;
 } UmbGemmFused;
@@ -276,6 +278,10 @@ typedef struct UmbOffload {
   umb_stream_t copy_stream;
   void* ev_copied[2];               /* hipEvent_t */
   void* ev_free[2];
+  int32_t* prefetched;              /* host int32[2] owned by the caller, initialised to {-1, -1} (NULL: no cross-forward
+                                       prefetch): the layers whose slabs the previous forward left in flight for this one.
+                                       The reference's (idx + 1) % num_layers copy (llama.py:203-209): the next forward's
+                                       first two layers stream while lm_head, sampling and the next draft tree run. */
 } UmbOffload;
 int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbOffload* off,
                               umb_stream_t stream);

@@ -3,6 +3,7 @@
   C3: Llama-3.1-70B-AWQ target (layers streamed from pinned host DRAM) + 1B draft, dynamic w16/b24/d16
 """
 import argparse, json, os, sys, time
+os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as ge

@@ -1,4 +1,6 @@
 import os, sys, time
+
+os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 sys.path.insert(0, '/root/repo')
 import torch
 import __graft_entry__ as ge

@@ -2,6 +2,8 @@
 shape, weights rotated over enough copies that every launch streams from HBM; then whole forwards of a model under
 hipGraph replay with both schedules (UMB_SCHED).  Usage: python scripts/ll_bench.py [1b] [70b] [8b] [fwd1b] [fwd70b]"""
 import os
+
+os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 import sys
 import time
 

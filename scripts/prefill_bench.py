@@ -1,5 +1,7 @@
 """Prefill (time to first token) of the target for a P-token prompt at different chunk sizes."""
 import os, sys, time
+
+os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as ge

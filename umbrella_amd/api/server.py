@@ -48,16 +48,41 @@ class APIServer:
         _log.info(TextColors.colorize(f"client {addr} disconnected", "cyan"))
 
     # -- the only thread that touches the engine ------------------------------------------------------------
+    def _validate(self, request: dict):
+        """Wire input is untrusted: token ids must be ints inside the vocabulary before they reach the embedding gather."""
+        ids = request.get("input_ids", None)
+        if ids is None:
+            return
+        vocab = getattr(self.engine, "vocab_size", None)
+        if not isinstance(ids, (list, tuple)) or not all(isinstance(i, int) and not isinstance(i, bool) for i in ids):
+            raise ValueError("input_ids must be a list of integers")
+        if vocab is not None and any(i < 0 or i >= vocab for i in ids):
+            raise ValueError(f"input_ids outside the vocabulary [0, {vocab})")
+
     def _answer(self, request: dict) -> dict:
         with self.queue_lock:
+            self._validate(request)
             result = self.engine.generate(**request)
         return dict(result, processed=True, response="Processed successfully")
 
     def process_queue(self):
+        """One worker owns the engine.  A request that fails -- bad argument types, a kernel error, free text with the id
+        tokenizer -- gets an error reply and the engine is reset; the worker (and every other client) carries on."""
         for addr, conn, request in iter(self.message_queue.get, None):
             try:
-                send_data(conn, self._answer(request), self.wire)
-            except OSError as err:
+                reply = self._answer(request)
+            except Exception as err:                                   # noqa: BLE001 -- per-request isolation
+                _log.error(TextColors.colorize(f"request from {addr} failed: {type(err).__name__}: {err}", "red"))
+                reply = {"processed": False, "response": f"{type(err).__name__}: {err}", "generated_text": "",
+                         "generated_tokens": [], "avg_accept_tokens": 0, "time_per_output_token": 0}
+                try:
+                    with self.queue_lock:
+                        self.engine.reset()
+                except Exception as rerr:                               # noqa: BLE001
+                    _log.error(TextColors.colorize(f"engine reset failed: {rerr}", "red"))
+            try:
+                send_data(conn, reply, self.wire)
+            except (OSError, TypeError, ValueError) as err:
                 _log.error(TextColors.colorize(f"reply to {addr} failed: {err}", "red"))
 
     def _ensure_engine(self):

@@ -282,6 +282,8 @@ enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 
 //  * epi 3 / 4 with S > 1: every split block publishes its fp32 partial tile, the LAST block to arrive on the
 //    n-group's counter sums the S partials in split order (deterministic) and runs the epilogue -- no reduce kernel.
 struct GemmFused {
+  int ssq_stride;          // row stride of ssq_in (0: ssq_groups)
+  int x_fm, out_fm;        // x / the SiLU output in FM (MFMA B-fragment) layout, lowlat.hip: the low-latency schedule's buffers
   const float* ssq_in; int ssq_groups; float ssq_dim; float eps;
   unsigned* counters;
   u16* h; u16* hw; const u16* norm_w; float* ssq_out; int ssq_out_stride;    // epi 4
@@ -339,7 +341,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
         const int tok = ((f >> 2) % TT) * 16 + j;
         const u32x4 z = {0u, 0u, 0u, 0u};
         const bool ok = tok < T && (FULL || kb0 + c * CB + kl < kb1);
-        xr[i] = ok ? *reinterpret_cast<const u32x4*>(xb + (long)tok * ldx + kl * 128 + (f & 3) * 32 + g * 8) : z;
+        if (fx.x_fm)    // fragment order: the B fragment of (k32-step, token tile) is one contiguous 1 KiB
+          xr[i] = (FULL || kb0 + c * CB + kl < kb1)
+                      ? reinterpret_cast<const u32x4*>(x)[((long)((kb0 + c * CB + kl) * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 64 + lane] : z;
+        else
+          xr[i] = ok ? *reinterpret_cast<const u32x4*>(xb + (long)tok * ldx + kl * 128 + (f & 3) * 32 + g * 8) : z;
       }
     };
     auto store_x = [&](int c) {
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     inv[tt] = 1.f;
     const int tok = tt * 16 + j;
     if (fx.ssq_in && tok < T) {
-      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      const float* sq = fx.ssq_in + (long)tok * (fx.ssq_stride ? fx.ssq_stride : fx.ssq_groups);
       float a = 0.f;
       for (int q = 0; q < fx.ssq_groups; q += 4) {          // groups are a multiple of 4 or padded with zeros
         const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q);
@@ -411,7 +417,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
             const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
             const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
             u16* act = reinterpret_cast<u16*>(out);
-            *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + (nt0 + r) * 8 + g * 2) = pack2<P>(a0, a1);
+            const int fa = (nt0 + r) * 8 + g * 2;
+            const long off = fx.out_fm ? ((((long)(fa >> 5) * TT + (tok >> 4)) * 64 + ((fa >> 3) & 3) * 16 + (tok & 15)) << 3) + (fa & 7)
+                                       : (long)tok * (N / 2) + fa;
+            *reinterpret_cast<unsigned*>(act + off) = pack2<P>(a0, a1);
           } else {
             if (epi == EPI_ROUND) {
               v *= inv[tt];
@@ -985,7 +994,7 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     const u16* xx = x + (long)t0 * ldx;
     float* oo = out + (long)t0 * ostride;      // out is [S][T][N] over the full T; split stride stays T
     GemmFused fx = fx0;                        // per-chunk views of the token-indexed side buffers
-    if (fx.ssq_in) fx.ssq_in += (long)t0 * fx.ssq_groups;
+    if (fx.ssq_in) fx.ssq_in += (long)t0 * (fx.ssq_stride ? fx.ssq_stride : fx.ssq_groups);
     if (fx.ssq_out) fx.ssq_out += (long)t0 * fx.ssq_out_stride;
     if (fx.h) fx.h += (long)t0 * N;
     if (fx.hw) fx.hw += (long)t0 * N;
@@ -1019,6 +1028,7 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   if (awq && (N % 64 || (R != 1 && (N / 16) % (4 * R)))) return UMB_EINVAL;
   GemmFused fx = {};
   if (fxc) {
+    fx.ssq_stride = fxc->pad0; fx.x_fm = fxc->pad1 & 1; fx.out_fm = (fxc->pad1 >> 1) & 1;
     fx.ssq_in = fxc->ssq_in; fx.ssq_groups = fxc->ssq_groups; fx.ssq_dim = fxc->ssq_dim; fx.eps = fxc->eps;
     fx.counters = fxc->counters; fx.h = (u16*)fxc->h; fx.hw = (u16*)fxc->hw; fx.norm_w = (const u16*)fxc->norm_w;
     fx.ssq_out = fxc->ssq_out; fx.ssq_out_stride = fxc->ssq_out_stride; fx.pos = fxc->pos; fx.slot = fxc->slot; fx.cosT = (const u16*)fxc->cosT;
@@ -1031,7 +1041,8 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
     if (epi == EPI_QKV && (!fx.pos || !fx.slot || !fx.q_out || !fx.kc || !fx.vt || fx.D % 4 || (fx.ssq_in && fx.ssq_groups % 4)))
       return UMB_EINVAL;
   }
-  if (fx.ssq_in && fx.ssq_groups % 4) return UMB_EINVAL;
+  if (fx.ssq_in && (fx.ssq_groups % 4 || fx.ssq_stride % 4)) return UMB_EINVAL;
+  if ((fx.x_fm || fx.out_fm) && T > 64) return UMB_EINVAL;      // FM buffers hold one launch of <= 64 tokens
   if (awq && dtype == UMB_F16)     // exact fp16 dequant in registers (same W as the reference's dequantize kernel)
     return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
   DISPATCH_DTYPE(dtype, {

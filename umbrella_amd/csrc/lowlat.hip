@@ -54,9 +54,11 @@ struct LLArgs {
   int Hq, Hkv, D, Lmax, rope_heads;
 };
 
-template <int AWQ, int R> struct LStage {
+template <int AWQ, int R> struct LStage {           // weights of one k-block (R n-tiles)
   u32x4 a[R][AWQ ? 1 : 4];
-  u32x4 m4[AWQ ? R : 1];       // 4 x {fp16 scale, fp16 zero} of output rows 4g .. 4g+3
+};
+template <int R> struct LMeta {                       // int4: 4 x {fp16 scale, fp16 zero} of output rows 4g .. 4g+3, per n-tile
+  u32x4 m4[R];
 };
 
 __device__ __forceinline__ unsigned and_or_b32(unsigned a, unsigned mask, unsigned magic_v) {
@@ -72,12 +74,12 @@ __device__ __forceinline__ int ll_rowmap_qkv(int n, int D, int rope_heads) {
   return head * D + ((dp & 1) ? (dp >> 1) + D / 2 : (dp >> 1));
 }
 
-// 8 waves per block.  TT = 1 (T <= 16: every draft level, the 13-node verify) is held to 128 registers so two blocks
-// share a CU (4 waves per SIMD); the wider token tilings may use the whole file (one block per CU).
+// 8 waves per block, up to 256 registers (two waves per SIMD): the operand rings want the registers more than the
+// kernel wants a second resident block -- bytes in flight per CU come from the ring depth.
 // PF = k-blocks of weights in flight per wave; the host guarantees that every wave owns the same number nk = KB / WK
 // of k-blocks and that nk is a multiple of PF, so the main loop has no predicate at all.
 template <typename P, int AWQ, int TT, int R, int PF>
-__global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLArgs a) {
+__global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NF = R * TT;                 // accumulator fragments per wave
   const int lane = threadIdx.x & 63;
@@ -112,13 +114,19 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
                   : (nt * (unsigned)KB) * 4096u;                              // dense [N/16][K/32] tiles, 4 per k-block
   }
   constexpr int NT_AUX = 2;                                            // non-temporal: weights are read once
+  auto load_meta = [&](LMeta<R>& mt, int kb) {
+    if constexpr (AWQ) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        mt.m4[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, voff_m, (int)((wofs[r] + (unsigned)kb * 4096u) >> 4), 0);   // 64 B per tile
+    }
+  };
   auto load_stage = [&](LStage<AWQ, R>& st, int kb) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const unsigned o = wofs[r] + (unsigned)kb * 4096u;               // both formats advance 4 KiB per k-block
       if (AWQ) {
         st.a[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voff, (int)o, NT_AUX);
-        st.m4[AWQ ? r : 0] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, voff_m, (int)(o >> 4), 0);   // 64 B of metadata per tile
       } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -126,18 +134,18 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
       }
     }
   };
-  auto load_x1 = [&](u32x4 (&xb)[TT][4], int kb, int s) {              // fragment(s) of k32-step s of k-block kb
+  auto load_x = [&](u32x4 (&xb)[TT][4], int kb) {                      // the 4 x TT B fragments of k-block kb (from L2)
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-      xb[tt][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, (int)(((unsigned)(kb * 4 + s) * TT + tt) * 1024u), 0);
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+        xb[tt][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, (int)(((unsigned)(kb * 4 + s) * TT + tt) * 1024u), 0);
   };
   unsigned magic_lo = P::MAGIC;                          // fp16 1024 / bf16 128: nibble at mantissa bits 0..3
   unsigned magic_hi = 0x54005400u;                       // fp16 64: nibble at mantissa bits 4..7 (fp16 only)
   if (AWQ) { asm volatile("" : "+v"(magic_lo)); asm volatile("" : "+v"(magic_hi)); }
-  // One k-block: k32-step major, so that the activation fragment of step s is dead after step s and is reloaded at once
-  // with the next k-block's (kb_next >= 0): a single activation buffer behaves like a double buffer.
-  auto compute = [&](const LStage<AWQ, R>& st, u32x4 (&xb)[TT][4], int kb_next, auto has_next) {
-    constexpr bool NEXT = decltype(has_next)::value;
+  // One k-block (k32-step major).
+  auto compute = [&](const LStage<AWQ, R>& st, const LMeta<R>& mt, const u32x4 (&xb)[TT][4]) {
     if constexpr (!AWQ) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -145,7 +153,6 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int r = 0; r < R; ++r) acc[r][tt] = P::mfma(st.a[r][s], xb[tt][s], acc[r][tt]);
-        if constexpr (NEXT) load_x1(xb, kb_next, s);
       }
     } else {
       constexpr bool HALF = std::is_same<P, F16>::value;
@@ -189,13 +196,12 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
           np[tt] = P::mfma(negc, xb[tt][s], np[tt]);
           sx[tt] = P::mfma(ones, xb[tt][s], sx[tt]);
         }
-        if constexpr (NEXT) load_x1(xb, kb_next, s);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const unsigned m = st.m4[AWQ ? r : 0][e];
+          const unsigned m = mt.m4[r][e];
           const float sc = (float)__builtin_bit_cast(_Float16, (u16)(m & 0xffffu));
           const float nz = -(float)__builtin_bit_cast(_Float16, (u16)(m >> 16));
 #pragma unroll
@@ -208,8 +214,18 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
 
   // ---- main loop: PF-deep weight ring; activations reloaded step by step inside compute().  Straight-line rings:
   // no branch inside, so the compiler's vmcnt bookkeeping is exact (at a control-flow join it waits for everything).
+  // Vector-memory loads return in issue order (one vmcnt counter): an activation fragment requested AFTER a deep weight
+  // prefetch cannot be consumed before that prefetch has landed.  So the activations ride in a ring of the SAME depth as
+  // the weights and are requested together with them -- a k-block's operands arrive together, PF k-blocks after their
+  // request, and nothing younger is ever waited for.  (First version: single activation buffer reloaded one k-block
+  // ahead -> every k-block paid the HBM latency of the weight stage issued just before it: 55 % of the wave cycles
+  // parked in s_waitcnt, profiles/r02_pmc_ll_gemm.txt.)
+  // The int4 metadata (16 B per lane and tile) rides in its own, shallower ring: PM k-blocks ahead are enough for
+  // 64-byte reads that follow the weights of the same k-block in the queue.
+  constexpr int PM = PF < 2 ? PF : 2;
   LStage<AWQ, R> st[PF];
-  u32x4 xb[TT][4];
+  LMeta<R> mt[PM];
+  u32x4 xr[PF][TT][4];
   // this wave's share of the producer's sums of squares (summed below, fixed order)
   float ssq_part[TT];
 #pragma unroll
@@ -224,25 +240,29 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
   }
   if (nk > 0) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) load_stage(st[i], wk + i * WK);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) load_x1(xb, wk, s);
+    for (int i = 0; i < PF; ++i) {
+      load_x(xr[i], wk + i * WK);
+      load_stage(st[i], wk + i * WK);
+      if (i < PM) load_meta(mt[i], wk + i * WK);
+    }
     int i0 = 0;
     for (; i0 + 2 * PF <= nk; i0 += PF) {
 #pragma unroll
       for (int s = 0; s < PF; ++s) {
         const int i = i0 + s;
-        compute(st[s], xb, wk + (i + 1) * WK, std::true_type{});
+        compute(st[s], mt[s % PM], xr[s]);
+        load_x(xr[s], wk + (i + PF) * WK);
         load_stage(st[s], wk + (i + PF) * WK);
+        load_meta(mt[s % PM], wk + (i + PM) * WK);
         __builtin_amdgcn_sched_barrier(0);       // one k-block per scheduling region: bounds the live ranges
       }
     }
 #pragma unroll
-    for (int s = 0; s + 1 < PF; ++s) {           // last ring: nothing left to refill
-      compute(st[s], xb, wk + (i0 + s + 1) * WK, std::true_type{});
+    for (int s = 0; s < PF; ++s) {               // last ring: nothing left to refill but the metadata
+      compute(st[s], mt[s % PM], xr[s]);
+      if (s + PM < PF) load_meta(mt[s % PM], wk + (i0 + s + PM) * WK);
       __builtin_amdgcn_sched_barrier(0);
     }
-    compute(st[PF - 1], xb, -1, std::false_type{});
   }
 
   // ---- in-block reduction over the WK slices (slice order), epilogue by wave (wn, 0)
@@ -394,6 +414,8 @@ __global__ __launch_bounds__(512, TT == 1 ? 4 : 2) void ll_gemm_kernel(const LLA
 // ------------------------------------------------------------------ plan: (R, WN, WK, NW) from the layer shape only
 // R n-tiles per wave, WN row groups x WK K-slices = NW waves per block.  Scored for an MI355X (256 CUs, 16 waves per
 // CU at <= 128 registers): whole rounds of blocks over the CUs, >= 8 waves per CU, >= 2 k-blocks per wave.
+static int ll_env_plan(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 extern "C" void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int* WK_out, int* NW_out) {
   const int NT = N / 16, KB = K / 128;
   int R = (awq && NT % 2 == 0 && NT >= 512) ? 2 : 1;
@@ -418,6 +440,14 @@ extern "C" void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int*
       if (score > best) { best = score; bWN = WN; bWK = WK; bNW = NW; }
     }
   }
+  // experiment knobs: UMB_LL_NW (waves per block: 4 or 8), UMB_LL_WK (K-slices per block)
+  static const int nw_env = ll_env_plan("UMB_LL_NW", 0), wk_env = ll_env_plan("UMB_LL_WK", 0);
+  if (nw_env == 4 || nw_env == 8) {
+    bNW = nw_env;
+    if (bWK > bNW) bWK = bNW;
+    bWN = bNW / bWK;
+  }
+  if (wk_env > 0 && wk_env <= bNW && (bNW % wk_env) == 0 && KB % wk_env == 0) { bWK = wk_env; bWN = bNW / bWK; }
   *R_out = R; *WN_out = bWN; *WK_out = bWK; *NW_out = bNW;
 }
 
@@ -439,13 +469,17 @@ static int ll_launch_pf(const LLArgs& a, int NW, hipStream_t st) {
   return UMB_OK;
 }
 
-// ring depth from the k-blocks per wave: the deepest of {4, 2, 1} that divides it and fits the registers of the variant
+// Ring depth from the k-blocks per wave: the deepest of {4, 2, 1} that divides it and fits the 256 registers of the
+// variant (weights and activations are both PF deep).  UMB_LL_PF caps it (experiments).
+static int ll_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 template <typename P, int AWQ, int TT, int R>
 static int ll_launch(const LLArgs& a, int NW, hipStream_t st) {
   const int nk = (a.K / 128) / a.WK;
-  constexpr int PFMAX = (TT == 4 && AWQ && R == 2) ? 1 : (TT == 4 || (AWQ && R == 2)) ? 2 : 4;
-  if (PFMAX >= 4 && nk % 4 == 0) return ll_launch_pf<P, AWQ, TT, R, PFMAX >= 4 ? 4 : 1>(a, NW, st);
-  if (PFMAX >= 2 && nk % 2 == 0) return ll_launch_pf<P, AWQ, TT, R, PFMAX >= 2 ? 2 : 1>(a, NW, st);
+  static const int pf_cap = ll_env("UMB_LL_PF", 8);
+  constexpr int PFMAX = TT == 1 ? 4 : (TT == 4 && AWQ) ? 1 : 2;
+  if (PFMAX >= 4 && pf_cap >= 4 && nk % 4 == 0) return ll_launch_pf<P, AWQ, TT, R, PFMAX >= 4 ? 4 : 1>(a, NW, st);
+  if (PFMAX >= 2 && pf_cap >= 2 && nk % 2 == 0) return ll_launch_pf<P, AWQ, TT, R, PFMAX >= 2 ? 2 : 1>(a, NW, st);
   return ll_launch_pf<P, AWQ, TT, R, 1>(a, NW, st);
 }
 

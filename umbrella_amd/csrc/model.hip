@@ -8,6 +8,7 @@
 //   down gemm(+residual, ...) ] -> lm_head gemm(+1/rms, fp32 logits)          = 5 launches per layer
 #include "../../include/umbrella_hip.h"
 #include "common.h"
+#include <cstdlib>
 
 #define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
@@ -119,6 +120,15 @@ static inline int ll_groups(const UmbLinear& l) {
   return l.N / 16 / R;
 }
 
+// gate/up on the LDS-shared split-K-family kernel (S = 1): when its grid of N / (64 R) four-wave blocks covers the chip.
+// UMB_LL_GU = ll | shared overrides (experiments).  Shape-only, so batch invariance is kept.
+static inline bool gu_on_shared_kernel(const UmbLinear& l) {
+  static const char* env = getenv("UMB_LL_GU");
+  if (env && env[0] == 'l') return false;
+  if (env && env[0] == 's') return l.S == 1;
+  return l.S == 1 && l.N / (64 * (l.R > 0 ? l.R : 1)) >= 256;
+}
+
 static int prologue_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
   if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
   return umb_embed_ll(ws->h, s->skip_embed ? nullptr : m->embed, m->H, m->V, m->Lmax, s->T, s->tokens, s->positions,
@@ -150,10 +160,19 @@ static int layer_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
   UmbGemmLL fo = {};
   fo.h = ws->h; fo.hw = ws->hw; fo.norm_w = ly.norm2; fo.ssq_out = ws->ssq; fo.ssq_out_stride = ws->ssq_stride;
   CK(umb_gemm_ll(nullptr, ws->attn, ly.o.w, ly.o.meta, T, ly.o.N, ly.o.K, ly.o.awq, 4, &fo, dt, st));
-  // 4. gate/up (rows interleaved at load): act = SiLU(gate / rms) * up / rms, FM layout
-  UmbGemmLL fg = {};
-  fg.ssq_in = ws->ssq; fg.ssq_groups = og; fg.ssq_in_stride = ws->ssq_stride; fg.ssq_dim = (float)m->H; fg.eps = m->eps;
-  CK(umb_gemm_ll(ws->act, ws->hw, ly.gu.w, ly.gu.meta, T, ly.gu.N, ly.gu.K, ly.gu.awq, 2, &fg, dt, st));
+  // 4. gate/up (rows interleaved at load): act = SiLU(gate / rms) * up / rms, FM layout.  A linear with enough n-tiles
+  // to fill the chip without any K split runs on the LDS-shared kernel of gemm.hip (4 waves share each activation
+  // fragment; 70B gate/up: 53 vs 65 us), reading and writing the same FM buffers.
+  if (gu_on_shared_kernel(ly.gu) && og % 4 == 0 && ws->ssq_stride % 4 == 0) {
+    UmbGemmFused fs = {};
+    fs.ssq_in = ws->ssq; fs.ssq_groups = og; fs.pad0 = ws->ssq_stride; fs.ssq_dim = (float)m->H; fs.eps = m->eps;
+    fs.pad1 = 3;                                            // x and the SiLU output in FM layout
+    CK(lin(ly.gu, ws->hw, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, &fs));
+  } else {
+    UmbGemmLL fg = {};
+    fg.ssq_in = ws->ssq; fg.ssq_groups = og; fg.ssq_in_stride = ws->ssq_stride; fg.ssq_dim = (float)m->H; fg.eps = m->eps;
+    CK(umb_gemm_ll(ws->act, ws->hw, ly.gu.w, ly.gu.meta, T, ly.gu.N, ly.gu.K, ly.gu.awq, 2, &fg, dt, st));
+  }
   // 5. down: h += d ; hw = h * (next layer's norm1 | final norm) ; sums of squares
   UmbGemmLL fd = {};
   fd.h = ws->h; fd.hw = ws->hw; fd.norm_w = next_norm; fd.ssq_out = ws->ssq; fd.ssq_out_stride = ws->ssq_stride;
@@ -231,13 +250,29 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
     if (hipEventRecord((hipEvent_t)off->ev_copied[buf], cs) != hipSuccess) return UMB_EHIP;
     return UMB_OK;
   };
-  // order the copy stream behind everything already queued on st that may still read the slabs
-  for (int b = 0; b < 2; ++b)
-    if (hipEventRecord((hipEvent_t)off->ev_free[b], st) != hipSuccess) return UMB_EHIP;
+  // the first two streamed layers of this range, in order
+  int first[2] = {-1, -1};
+  for (int l = lb, n = 0; l < le && n < 2; ++l)
+    if (off->host_slabs[l]) first[n++] = l;
+  // Cross-forward prefetch (the reference's loop copies layer (idx + 1) % num_layers, llama.py:203-209: layer 0 of the
+  // NEXT forward is in flight while lm_head, sampling and the next draft tree run).  The previous forward left its
+  // epilogue copies of exactly these two layers in the slabs / on the copy stream: nothing to issue, and nothing on the
+  // compute stream gates them.
+  int32_t* pf = off->prefetched;
+  const bool have = pf && pf[0] == first[0] && pf[1] == first[1] && first[0] >= 0;
   int next = lb, issued = 0, used = 0;
   auto advance = [&]() { while (next < le && off->host_slabs[next] == nullptr) ++next; };
   advance();
-  for (int i = 0; i < 2 && next < le; ++i) { CK(issue_copy(next, issued & 1)); ++issued; ++next; advance(); }
+  if (have) {
+    for (int i = 0; i < 2 && next < le; ++i) { ++issued; ++next; advance(); }
+  } else {
+    // cold start (or a different layer range): order the copy stream behind everything already queued on st that may
+    // still read the slabs, then fetch the first two layers
+    for (int b = 0; b < 2; ++b)
+      if (hipEventRecord((hipEvent_t)off->ev_free[b], st) != hipSuccess) return UMB_EHIP;
+    for (int i = 0; i < 2 && next < le; ++i) { CK(issue_copy(next, issued & 1)); ++issued; ++next; advance(); }
+  }
+  if (pf) pf[0] = pf[1] = -1;
 
   const bool ll = use_ll(ws, s);
   int sg = 4;
@@ -257,6 +292,14 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       if (hipEventRecord((hipEvent_t)off->ev_free[buf], st) != hipSuccess) return UMB_EHIP;
       if (next < le) { CK(issue_copy(next, buf)); ++issued; ++next; advance(); }
     }
+  }
+  // Epilogue: the next forward's first two slabs go out NOW, on the copy stream only -- each waits (on that stream) for
+  // the ev_free of the last layer that read its slab, which was recorded above; the compute stream carries on with the
+  // lm_head, the sampling kernels and the next draft tree while the link is busy.  Slab parity restarts at 0.
+  if (pf && first[0] >= 0) {
+    CK(issue_copy(first[0], 0));
+    if (first[1] >= 0) CK(issue_copy(first[1], 1));
+    pf[0] = first[0]; pf[1] = first[1];
   }
   if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;

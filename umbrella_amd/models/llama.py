@@ -27,6 +27,19 @@ from ..attn.cache import TreeKVCache
 from .base import LLMBase
 from .config import KNOWN, LlamaCfg, rope_tables
 from .synthetic import LINEARS, linear_shapes, synth_awq_tensors, synth_tensor
+from ..logging_config import setup_logger
+
+logger = setup_logger()
+
+
+def _resolve_hub_snapshot(model_name: str):
+    """hub id -> local snapshot directory from the Hugging Face cache (no network), or None."""
+    try:
+        from huggingface_hub import snapshot_download
+        path = snapshot_download(model_name, local_files_only=True)
+        return path if os.path.exists(os.path.join(path, "config.json")) else None
+    except Exception:
+        return None
 
 
 def _align(n, a=256):
@@ -172,6 +185,10 @@ class Llama(LLMBase):
         # sched "ll": low-latency schedule for forwards of <= 64 rows -- 5 launches / layer, whole-K workgroups with the
         # layer's elementwise work as GEMM epilogues, activations in MFMA fragment order (csrc/lowlat.hip)
         self.sched = os.environ.get("UMB_SCHED", "ll")
+        if config is None and not os.path.isdir(model_name) and state_dict is None:
+            local = _resolve_hub_snapshot(model_name)             # HF cache, offline
+            if local is not None:
+                self.model_name = model_name = local
         if config is not None:
             self.config = config
         elif os.path.isdir(model_name):
@@ -212,8 +229,13 @@ class Llama(LLMBase):
                 with safe_open(index[name], "pt") as h:
                     return h.get_tensor(name).to(dev)
             return fetch
-        if os.environ.get("UMBRELLA_SYNTHETIC", "1") != "1":
-            raise FileNotFoundError(f"no checkpoint for {self.model_name} and UMBRELLA_SYNTHETIC=0")
+        if os.environ.get("UMBRELLA_SYNTHETIC", "0") != "1":
+            raise FileNotFoundError(
+                f"no checkpoint for '{self.model_name}': not a local directory and not in the Hugging Face cache "
+                "(HF_HOME / HF_HUB_CACHE).  Set UMBRELLA_SYNTHETIC=1 to run on seeded random weights of the same "
+                "shapes (benchmarks / tests only -- the output is meaningless text).")
+        logger.warning(f"SYNTHETIC WEIGHTS: '{self.model_name}' is initialised with seeded random tensors "
+                       "(UMBRELLA_SYNTHETIC=1); generated tokens carry no meaning")
         gen = torch.Generator(device=dev).manual_seed(self._seed)
         # GPT-2 style scaled init: projections that write into the residual stream get std / sqrt(2L),
         # which keeps a random-init 80-layer stack from chaotically amplifying 1-ulp differences
@@ -284,11 +306,15 @@ class Llama(LLMBase):
         H, V = c.hidden_size, c.vocab_size
         if reseed is not None:
             reseed.manual_seed(self._seed * 1000003)
-        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed").to(dt).contiguous() \
+        # checkpoints may carry more rows than config.vocab_size (Qwen2.5 7B+: 152064 rows, vocabulary 151936): the
+        # logits buffer, arg-max, top-k and sampling all work on V columns, so both matrices are cut to V rows
+        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed")[:V].to(dt).contiguous() \
             if (self.is_first or (self.is_last and c.tie_word_embeddings)) else None
         if self.is_last:
-            head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head").to(dt)
+            head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head")[:V].to(dt)
+            assert head_w.shape == (V, H), (tuple(head_w.shape), V, H)
             self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)
+            assert self.lm_head.N == V
             del head_w
             self.norm_weight = fetch("model.norm.weight", (H,), "norm").to(dt).contiguous()
         else:
@@ -375,6 +401,11 @@ class Llama(LLMBase):
             off.copy_stream = self.load_stream.cuda_stream
             off.ev_copied[0], off.ev_copied[1] = self._events[0].cuda_event, self._events[1].cuda_event
             off.ev_free[0], off.ev_free[1] = self._events[2].cuda_event, self._events[3].cuda_event
+            # cross-forward prefetch state: which two layers the previous forward left streaming (UMB_OFFLOAD_PREFETCH=0:
+            # the reference-free baseline that refetches them behind the draft's kernels)
+            self._pf_state = (C.c_int32 * 2)(-1, -1)
+            if os.environ.get("UMB_OFFLOAD_PREFETCH", "1") != "0":
+                off.prefetched = C.cast(self._pf_state, C.POINTER(C.c_int32))
             self._off = off
         self.reserve(self.CHUNK)
         torch.cuda.synchronize()

@@ -289,8 +289,20 @@ class PipelinedStaticEngine(_Static):
         self._stage_model, self._comm = stage_model, comm
 
     def initialize(self):
+        self._require_greedy()
         self._target_model = PipelinedTarget(self._stage_model, self._comm, self)
         super().initialize()
+
+    def _require_greedy(self):
+        """The last stage returns arg-max token ids (T ints per verify) instead of [T, V] logits; sampling settings
+        that would need the logits on rank 0 are refused loudly rather than silently ignored."""
+        if not self._greedy():
+            raise ValueError("the layer-sharded engine verifies greedily: temperature >= 0.05 / repetition_penalty > 1.01 "
+                             "are not supported (BASELINE config 5 is greedy)")
+
+    def update_generation_args(self, **generation_args):
+        super().update_generation_args(**generation_args)
+        self._require_greedy()
 
     def _feed(self, lo, hi):
         ids = self.tokens[lo:hi]

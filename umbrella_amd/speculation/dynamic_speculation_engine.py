@@ -49,7 +49,9 @@ class DynamicSpeculationEngine(HipEngine):
         self.draft_rows = W
         self._load_models(dict(offload=False), dict(offload=bool(self.offload_target)))
         if getattr(self.target_model, "_off", None) is not None:
-            self.use_graph = False                                  # event-ordered copy stream is launched eagerly
+            # the event-ordered copy stream of the streamed verify is launched eagerly; the draft tree (depth + 1 small
+            # forwards, top-k and beam kernels: ~1.5 k launches) still replays as one hipGraph
+            self.graph_scope = "draft"
         self._alloc_state(T, Dp + 1)
         self.enable_override = False
 

@@ -43,6 +43,7 @@ class HipEngine(BaseEngine):
         self.repetition_penalty = kwargs.pop("repetition_penalty", 1.0)
         self.topk = kwargs.pop("topk", 32)
         self.use_graph = kwargs.pop("hip_graph", True)
+        self.graph_scope = "iteration"        # "draft": only the draft tree is captured (layer-streamed targets)
         self.seed = kwargs.pop("seed", 0)
         # optional injected models / tokenizer (tests, synthetic benches)
         self._draft_model = kwargs.pop("draft_model_obj", None)
@@ -77,7 +78,9 @@ class HipEngine(BaseEngine):
             try:
                 from transformers import AutoTokenizer
                 self.tokenizer = AutoTokenizer.from_pretrained(self.target_model_name, local_files_only=True)
-            except Exception:
+            except Exception as e:
+                logger.warning(f"NO TOKENIZER for '{self.target_model_name}' ({type(e).__name__}): falling back to the "
+                               "id tokenizer -- text is read and written as space-separated token ids")
                 self.tokenizer = IdTokenizer()       # no tokenizer files offline: ids <-> "12 7 99" text
 
     def _alloc_state(self, tree_size, max_path):
@@ -202,6 +205,15 @@ class HipEngine(BaseEngine):
 
     def _iteration_launch(self):
         self.build_tree()
+        if self.graph_scope == "draft":
+            return
+        self._verify_forward()
+        self._sample()
+        self._commit()
+
+    def _iteration_tail(self):
+        """What runs eagerly after a draft-only graph: the streamed verify forward (event-ordered copies on the side
+        stream cannot live inside the graph), sampling and the commit."""
         self._verify_forward()
         self._sample()
         self._commit()
@@ -239,6 +251,8 @@ class HipEngine(BaseEngine):
             self._graph.replay()
         else:
             self._iteration_launch()
+        if self.graph_scope == "draft":
+            self._iteration_tail()
         return self._finish_iteration()
 
     def _finish_iteration(self) -> bool:
