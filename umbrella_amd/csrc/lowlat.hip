@@ -61,11 +61,10 @@ template <int R> struct LMeta {                       // int4: 4 x {fp16 scale, 
   u32x4 m4[R];
 };
 
-__device__ __forceinline__ unsigned and_or_b32(unsigned a, unsigned mask, unsigned magic_v) {
-  unsigned r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(magic_v));
-  return r;
-}
+// (a & mask) | magic.  Plain C on purpose: the result feeds an MFMA operand directly, and the VALU-write -> MFMA-read
+// wait states are only inserted for instructions the compiler can see (an inline-asm v_and_or_b32 here produced wrong
+// columns at some ring depths).  With `magic` pinned in a VGPR the pattern still selects to one v_and_or_b32.
+__device__ __forceinline__ unsigned and_or_b32(unsigned a, unsigned mask, unsigned magic_v) { return (a & mask) | magic_v; }
 
 // packed source row of HF feature order (inverse use: bias lookup) -- same map as gemm.hip rowmap()
 __device__ __forceinline__ int ll_rowmap_qkv(int n, int D, int rope_heads) {
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
   // Streams: buffer loads with one descriptor per array, a 32-bit lane offset (VGPR) and a wave-uniform 32-bit byte
   // offset (SGPR) -- no per-load 64-bit VALU address arithmetic, no address registers.  (Arrays are < 4 GiB.)
   const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.w), 0, 0xffffffffu, 0x00020000);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.x), 0, 0xffffffffu, 0x00020000);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.x), 0, (unsigned)(TT * 16 * 2) * (unsigned)a.K, 0x00020000);   // exact size: see load_x
   const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.meta), 0, 0xffffffffu, 0x00020000);
   const int voff = lane * 16, voff_m = g * 16;
   unsigned wofs[R];                                                    // byte offset of k-block 0 of n-tile r
@@ -134,12 +133,20 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
       }
     }
   };
+  // The B fragment's lane (g, j) carries token tt * 16 + j.  Lanes of tokens >= T get an offset beyond the buffer
+  // descriptor's num_records: the load returns 0 for them without touching memory (their MFMA columns are never
+  // stored) -- a 3-row draft level moves 256 B per fragment instead of 1 KiB through the CU's vector-memory path, which
+  // with 8 private K-slices per block is what bounds the small-N linears (one CU sustains ~50 GB/s).  No branch, no
+  // exec juggling: the bounds check of the buffer instruction does it.
+  int voff_x[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) voff_x[tt] = (tt * 16 + j < a.T) ? voff : (int)0x80000000;
   auto load_x = [&](u32x4 (&xb)[TT][4], int kb) {                      // the 4 x TT B fragments of k-block kb (from L2)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt)
-        xb[tt][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff, (int)(((unsigned)(kb * 4 + s) * TT + tt) * 1024u), 0);
+        xb[tt][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff_x[tt], (int)(((unsigned)(kb * 4 + s) * TT + tt) * 1024u), 0);
   };
   unsigned magic_lo = P::MAGIC;                          // fp16 1024 / bf16 128: nibble at mantissa bits 0..3
   unsigned magic_hi = 0x54005400u;                       // fp16 64: nibble at mantissa bits 4..7 (fp16 only)

@@ -9,8 +9,18 @@
 #include "../../include/umbrella_hip.h"
 #include "common.h"
 #include <cstdlib>
+#include <cstdio>
 
-#define CK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+// UMB_DEBUG_SYNC=1: synchronise after every launch and name the first one that fails (eager launches only)
+static inline int dbg_sync(const char* what, hipStream_t st) {
+  static const bool on = getenv("UMB_DEBUG_SYNC") != nullptr;
+  if (!on) return 0;
+  const hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { fprintf(stderr, "[umb] %s failed: %s\n", what, hipGetErrorString(e)); return UMB_EHIP; }
+  fprintf(stderr, "[umb] ok %s\n", what);
+  return 0;
+}
+#define CK(x) do { int rc__ = (x); if (rc__) return rc__; rc__ = dbg_sync(#x, st); if (rc__) return rc__; } while (0)
 
 // split count actually used: the plan's S (a function of the layer shape only, so T <= 64 results are batch
 // invariant); the wide verify (T > 64) takes the S <= plan that fills the verify kernel's block slots once (gemm.hip)
