@@ -179,48 +179,65 @@ template <typename P, int AWQ, int TT, int R>
 __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const u32x4* xf, int lane,
                                               f32x4 (&acc)[R][TT]) {
   if (AWQ == 1) {
-    // folded dequant (any activation dtype): needs per-token sums, small TT only
+    // folded dequant (any activation dtype): the MFMA runs on the raw codes with a magic exponent and per 128-k group
+    //   out += s * ( sum_k (c_k + q_k) x_k - sum_k c_k x_k - z * sum_k x_k ),
+    // the two x-only sums from MFMAs against constant fragments (shared by the R tiles).  fp16: nibbles at mantissa
+    // bits 0..3 take the magic 1024, nibbles at bits 4..7 the magic 64 -> 5 VALU per 8 weights (1 shift + 4 v_and_or)
+    // instead of 13 for the exact in-register dequant of AWQ == 2; bf16 (7 mantissa bits): magic 128, 3 shifts.
+    constexpr bool HALF = std::is_same<P, F16>::value;
     u32x4 b[TT][4];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
+    const unsigned nlo = HALF ? 0xE400E400u : 0xC300C300u;           // -1024 | -128
+    const unsigned nhi = HALF ? 0xD400D400u : 0xC300C300u;           // -64   | -128
+    const u32x4 negc = {nlo, nhi, nlo, nhi};
     const u32x4 ones = {P::ONE2, P::ONE2, P::ONE2, P::ONE2};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 xs[TT];
+    unsigned magic_lo = P::MAGIC, magic_hi = 0x54005400u;
+    asm volatile("" : "+v"(magic_lo));                               // pinned in VGPRs: (w & mask) | magic selects v_and_or_b32
+    asm volatile("" : "+v"(magic_hi));
+    f32x4 xs[TT], np[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
-      xs[tt] = zero;
+      xs[tt] = zero; np[tt] = zero;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
+      for (int s = 0; s < 4; ++s) {
+        xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
+        np[tt] = P::mfma(negc, b[tt][s], np[tt]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       f32x4 ga[TT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) ga[tt] = zero;
+      for (int tt = 0; tt < TT; ++tt) ga[tt] = np[tt];                // C-in: - sum_k c_k x_k
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const unsigned w = st.a[r][0][s];
         u32x4 f;
-        f[0] = (w & 0x000F000Fu) | P::MAGIC;
-        f[1] = ((w >> 4) & 0x000F000Fu) | P::MAGIC;
-        f[2] = ((w >> 8) & 0x000F000Fu) | P::MAGIC;
-        f[3] = ((w >> 12) & 0x000F000Fu) | P::MAGIC;
+        if constexpr (HALF) {
+          const unsigned w8 = w >> 8;
+          f[0] = (w & 0x000F000Fu) | magic_lo;
+          f[1] = (w & 0x00F000F0u) | magic_hi;
+          f[2] = (w8 & 0x000F000Fu) | magic_lo;
+          f[3] = (w8 & 0x00F000F0u) | magic_hi;
+        } else {
+          f[0] = (w & 0x000F000Fu) | magic_lo;
+          f[1] = ((w >> 4) & 0x000F000Fu) | magic_lo;
+          f[2] = ((w >> 8) & 0x000F000Fu) | magic_lo;
+          f[3] = ((w >> 12) & 0x000F000Fu) | magic_lo;
+        }
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) ga[tt] = P::mfma(f, b[tt][s], ga[tt]);
       }
-      float sc[4], zo[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sc[e] = F16::to_f((u16)(st.m4[r][e] & 0xffffu));
-        zo[e] = F16::to_f((u16)(st.m4[r][e] >> 16)) + P::MAGIC_OFF;
-      }
+        const float sc = F16::to_f((u16)(st.m4[r][e] & 0xffffu));
+        const float nz = -F16::to_f((u16)(st.m4[r][e] >> 16));
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const float sx = xs[tt][0];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[r][tt][e] += sc[e] * (ga[tt][e] - zo[e] * sx);
+        for (int tt = 0; tt < TT; ++tt) acc[r][tt][e] = fmaf(sc, fmaf(nz, xs[tt][e], ga[tt][e]), acc[r][tt][e]);
       }
     }
     return;
@@ -1043,7 +1060,13 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   }
   if (fx.ssq_in && (fx.ssq_groups % 4 || fx.ssq_stride % 4)) return UMB_EINVAL;
   if ((fx.x_fm || fx.out_fm) && T > 64) return UMB_EINVAL;      // FM buffers hold one launch of <= 64 tokens
-  if (awq && dtype == UMB_F16)     // exact fp16 dequant in registers (same W as the reference's dequantize kernel)
+  // fp16 int4: exact in-register dequant (bit-identical weights to awq_ext.dequantize_weights_cuda).  The folded form
+  // s * sum (q - z) x (5 instead of 13 VALU per 8 weights, UMB_AWQ_FOLDED=1, T <= 64) was measured SLOWER in this
+  // kernel: its per-row metadata quad and the two constant-fragment MFMA chains cost 256 registers (2 waves per SIMD
+  // instead of 3.5) -- 70B gate/up 83-85 vs 66-67 us on the same box; it is what the low-latency family uses, where the
+  // register budget is spent on operand rings anyway.
+  static const bool awq_folded = getenv("UMB_AWQ_FOLDED") != nullptr;
+  if (awq && dtype == UMB_F16 && !(awq_folded && T <= 64))
     return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
   DISPATCH_DTYPE(dtype, {
     if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
