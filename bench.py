@@ -79,95 +79,143 @@ def run_steps(eng, steps):
 
 
 def kernel_roofline(eng, reps=40):
-    """Live HIP-event timing of the dominant kernel: the target's int4 (or bf16) skinny GEMMs at the
-    verify shape, rotating over the layers so weights come from HBM, not the 256 MB Infinity Cache."""
+    """Live HIP-event timing of the target's four layer linears at the verify shape, each through the kernel (and split
+    count / epilogue) the model's schedule actually launches, rotating over the layers so weights come from HBM, not
+    the 256 MB Infinity Cache.  Events are recorded on the stream the kernels are launched on (torch's current stream)."""
     from umbrella_amd import _lib
+    from umbrella_amd.models.llama import ll_plan, to_fm
     m = eng.target_model
     T = eng.tree_size
+    ll = getattr(m, "sched", "") == "ll" and not m.fused and T <= 64
+    dt = _lib.dtype_code(m.dtype)
     res = {}
-    x_by_k = {}
+    L = m.num_layers
+    lib = _lib.load()
     for key in ("qkv", "o", "gu", "down"):
         lin0 = m.layers[0][key]
-        x = x_by_k.setdefault(lin0.K, torch.randn(T, lin0.K, device=m.device).to(m.dtype))
+        N, K = lin0.N, lin0.K
+        x = torch.randn(T, K, device=m.device).to(m.dtype)
+        xfm = to_fm(x)
         part = m._bufs["partial"]
-        per_launch = (lin0.N * lin0.K // 2 + (lin0.N // 16) * (lin0.K // 128) * 64) if lin0.awq else lin0.N * lin0.K * 2
-        L = m.num_layers
-
-        def launch(i):
-            ln = m.layers[i % L][key]
-            _lib.call("umb_gemm", part, x, x.stride(0), ln.w, ln.meta, T, ln.N, ln.K, ln.awq, ln.S, ln.R, 0,
-                      _lib.dtype_code(m.dtype))
+        per_launch = (N * K // 2 + (N // 16) * (K // 128) * 64) if lin0.awq else N * K * 2
+        h = torch.zeros(T, N, dtype=m.dtype, device=m.device)
+        hw = torch.zeros(64 * N, dtype=m.dtype, device=m.device)
+        nw = torch.ones(N, dtype=m.dtype, device=m.device)
+        ssq = torch.ones(T, max(N // 16, K // 16, 4), dtype=torch.float32, device=m.device)
+        act = torch.zeros(64 * max(N // 2, 8), dtype=m.dtype, device=m.device)
+        info = {"family": "split-K", "R": lin0.R, "S": lin0.S}
+        if ll and key == "gu" and lin0.S == 1 and N // (64 * lin0.R) >= 256:
+            # low-latency schedule, large-N gate/up: LDS-shared kernel, FM in / FM out, 1/rms from the sums of squares
+            fs = _lib.UmbGemmFused()
+            fs.ssq_in, fs.ssq_groups, fs.pad0, fs.ssq_dim, fs.eps, fs.pad1 = ssq.data_ptr(), K // 32, ssq.shape[1], float(K), 1e-5, 3
+            launch = lambda ln: _lib.call("umb_gemm_fused", act, xfm, K, ln.w, ln.meta, T, N, K, ln.awq, 1, ln.R, 2, fs, dt)
+            info = {"family": "split-K kernel (S=1, FM buffers)", "R": lin0.R, "S": 1}
+        elif ll:
+            R, WN, WK, NW = ll_plan(N, K, bool(lin0.awq))
+            fx = _lib.UmbGemmLL()
+            if key in ("o", "down"):
+                fx.h, fx.hw, fx.norm_w, fx.ssq_out, fx.ssq_out_stride = h.data_ptr(), hw.data_ptr(), nw.data_ptr(), ssq.data_ptr(), ssq.shape[1]
+                epi, out = 4, None
+            elif key == "gu":
+                fx.ssq_in, fx.ssq_groups, fx.ssq_in_stride, fx.ssq_dim, fx.eps = ssq.data_ptr(), K // 32, ssq.shape[1], float(K), 1e-5
+                epi, out = 2, act
+            else:
+                epi, out = 0, part                      # qkv: the GEMM itself (RoPE / KV append epilogue writes only kilobytes)
+            launch = lambda ln: _lib.call("umb_gemm_ll", out, xfm, ln.w, ln.meta, T, N, K, ln.awq, epi, fx, dt)
+            info = {"family": "low-latency", "R": R, "WN": WN, "WK": WK}
+        else:
+            S = lin0.S
+            if key in ("o", "down"):                    # model.hip eff_s(): split count of the row-reduced linears
+                cap = max(K // 1792, 4)
+                if S > cap and (N // (64 * max(lin0.R, 1))) * cap >= 256:
+                    S = cap
+            epi = 2 if key == "gu" else 0
+            out = act if key == "gu" else part
+            launch = lambda ln: _lib.call("umb_gemm", out, x, x.stride(0), ln.w, ln.meta, T, N, K, ln.awq, S, ln.R, epi, dt)
+            info = {"family": "split-K", "R": lin0.R, "S": S}
         for i in range(4):
-            launch(i)
+            launch(m.layers[i % L][key])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for i in range(reps):
-            launch(i + 4)
+            launch(m.layers[(i + 4) % L][key])
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000.0 / reps
-        res[key] = dict(N=lin0.N, K=lin0.K, R=lin0.R, S=lin0.S, bytes=per_launch, us=us, gbs=per_launch / us / 1e3)
+        res[key] = dict(N=N, K=K, bytes=per_launch, us=us, gbs=per_launch / us / 1e3, **info)
     return res
 
 
-def cpu_baseline(wl, gm, accept_len, threads):
-    """Oracle ("port") timed on host cores on a bounded sample of the same workload: one static-tree
-    iteration with the target truncated to 1 of its layers and the draft to 2 (per-layer cost extrapolated
-    linearly; embedding + lm_head timed in full).  AWQ linears are dequantised once at load (what a CPU port
-    would do) and all arithmetic is fp32 on the torch CPU backend."""
+def _oracle_state(cfg, layers, alias):
+    """fp32 random state dict for the oracle; with alias=True the `layers` decoder layers share one set of tensors
+    (full-depth arithmetic and memory traffic -- a 70B layer is 3.4 GB in fp32, far beyond any cache -- at one
+    layer's RAM)."""
+    from umbrella_amd.models.synthetic import linear_shapes
+
+    def rnd(n, k):      # timing only: a materialised rank-1 random matrix costs one pass over memory instead of a Gaussian draw per element
+        return (torch.randn(n, 1) * 0.14) * (torch.randn(1, k) * 0.14)
+    sd = {"model.embed_tokens.weight": rnd(cfg.vocab_size, cfg.hidden_size),
+          "model.norm.weight": torch.ones(cfg.hidden_size)}
+    if not cfg.tie_word_embeddings:
+        sd["lm_head.weight"] = rnd(cfg.vocab_size, cfg.hidden_size)
+    first = {}
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        for ln, (n, k) in linear_shapes(cfg).items():
+            key = ln + ".weight"
+            if not alias or i == 0:
+                first[key] = rnd(n, k)
+            sd[p + key] = first[key]
+        sd[p + "input_layernorm.weight"] = torch.ones(cfg.hidden_size)
+        sd[p + "post_attention_layernorm.weight"] = torch.ones(cfg.hidden_size)
+    return sd
+
+
+def cpu_baseline(wl, gm, accept_len, threads, budget_s=30.0):
+    """Oracle ("port": torch CPU fp32, AWQ dequantised at load as a CPU port would) MEASURED end to end on the host
+    cores on a bounded sample of the same workload: one whole static-tree iteration -- every draft forward of the
+    iteration on the full 16-layer draft and the T-row verify through ALL target layers + lm_head -- at a 128-token
+    context.  The 80 target layers alias one layer's tensors (RAM: a 70B model is 280 GB in fp32), which changes neither
+    the arithmetic nor the memory traffic (3.4 GB per layer, no cache holds it).  tokens/s = accept_len / iteration."""
     import copy
     from oracle.model import OracleLlama
     from umbrella_amd.models.config import KNOWN, rope_inv_freq
-    from umbrella_amd.models.synthetic import linear_shapes
     torch.set_num_threads(threads)
     T = gm["size"]
+    P = 128
 
-    def time_model(name, layers, rows_list):
+    def build(name, alias):
         cfg = copy.copy(KNOWN[name])
-        full_layers = cfg.num_hidden_layers
-        cfg.num_hidden_layers = layers
-        sd = {"model.embed_tokens.weight": torch.randn(cfg.vocab_size, cfg.hidden_size) * 0.02,
-              "model.norm.weight": torch.ones(cfg.hidden_size)}
-        if not cfg.tie_word_embeddings:
-            sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
-        for i in range(layers):
-            p = f"model.layers.{i}."
-            for ln, (n, k) in linear_shapes(cfg).items():
-                sd[p + ln + ".weight"] = torch.randn(n, k) * 0.02
-            sd[p + "input_layernorm.weight"] = torch.ones(cfg.hidden_size)
-            sd[p + "post_attention_layernorm.weight"] = torch.ones(cfg.hidden_size)
+        sd = _oracle_state(cfg, cfg.num_hidden_layers, alias)
         inv, sc = rope_inv_freq(cfg)
-        m = OracleLlama(cfg, sd, inv, sc, max_length=256, dtype=torch.float32)
-        P = 128                                   # prefix already "in the cache" (zeros: timing only)
-        total = 0.0
-        for rows in rows_list:
-            ids = torch.randint(3, 1000, (1, rows))
-            pos = torch.arange(P, P + rows)[None]
-            mk = torch.ones(rows, 256, dtype=torch.bool)
-            best_all, best_head = 1e9, 1e9
-            for _ in range(2):                    # second pass = warm caches / thread pool
-                m.kv_cache.kv_offset = P
-                t0 = time.time()
-                m.inference(ids, pos, mk, torch.arange(P, P + rows))
-                best_all = min(best_all, time.time() - t0)
-                nl, m.num_layers = m.num_layers, 0
-                m.kv_cache.kv_offset = P
-                t0 = time.time()
-                m.inference(ids, pos, mk, torch.arange(P, P + rows))
-                best_head = min(best_head, time.time() - t0)
-                m.num_layers = nl
-            total += (best_all - best_head) / layers * full_layers + best_head
-        return total
+        return OracleLlama(cfg, sd, inv, sc, max_length=256, dtype=torch.float32)
+
+    def forward(m, rows):
+        ids = torch.randint(3, 1000, (1, rows))
+        pos = torch.arange(P, P + rows)[None]
+        mk = torch.ones(rows, 256, dtype=torch.bool)
+        m.kv_cache.kv_offset = P
+        t0 = time.time()
+        m.inference(ids, pos, mk, torch.arange(P, P + rows))
+        return time.time() - t0
 
     widths = [len(x) for x in gm["roots"]]
-    t_draft = time_model(wl["draft"], 2, widths)
-    t_target = time_model(wl["target"], 1, [T])
+    draft = build(wl["draft"], alias=False)
+    forward(draft, 1)                                      # warm the thread pool / allocator
+    t_draft = sum(forward(draft, w) for w in widths)       # the reference schedule: one draft forward per level
+    del draft
+    target = build(wl["target"], alias=True)
+    t_target = forward(target, T)
+    layers = target.num_layers
+    del target
     it = t_draft + t_target
     return {"value": round(accept_len / it, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (torch CPU fp32, AWQ dequantised at load) on 1 static {len(widths)-1}-level iteration: draft "
-                      f"truncated to 2 of its layers, target to 1 of its layers, per-layer time extrapolated linearly, "
-                      f"embedding + lm_head timed in full; extrapolated iteration {it:.2f} s at the same accept_len {accept_len:.2f}"}
+            "iteration_s": round(it, 3), "draft_s": round(t_draft, 3), "verify_s": round(t_target, 3),
+            "sample": f"1 whole static iteration measured end to end with the oracle (torch CPU fp32): {len(widths)} draft "
+                      f"forwards (rows {widths}) on the full draft + the {T}-row verify through all {layers} target layers "
+                      f"and the lm_head, context 128; target layers alias one layer's fp32 tensors (RAM), same arithmetic "
+                      f"and traffic; tokens/s at the GPU run's accept_len {accept_len:.2f}"}
 
 
 def main():
@@ -294,24 +342,37 @@ def main():
                           "parallelism": "1 engine per GPU (replicas)" if world > 1 else "single GPU"},
                "accept_len": round(accept_len, 3), "value_raw_draft": round(raw_tps, 2),
                "accept_len_raw_draft": round(raw_accept, 3), "oracle_draft_divergence": getattr(eng, "diverged", 0), "oracle_draft_passes": passes,
+               "schedule": getattr(m, "sched", "split"),
                "draft_forwards_per_iter": n_fwd, "iter_bytes_GB": round(bytes_iter / 1e9, 3),
                "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if not args.no_roofline:
             kr = kernel_roofline(eng)
             dom = max(kr.values(), key=lambda r: r["bytes"])
             tot_b, tot_us = sum(r["bytes"] for r in kr.values()), sum(r["us"] for r in kr.values())
+            # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
+            # the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md); it is
+            # only reported while the kernel source it was taken from is unchanged (sha256 of csrc/gemm.hip recorded there)
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm70b_traffic.json")
-            if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
-                with open(pmc) as f:                      # PMC pass is a separate rocprofv3 run (see profiles/README.md)
-                    traffic, tsrc = json.load(f)["gate_up_traffic_bytes"], "profiles/r01_pmc_gemm70b_traffic.json"
-            out["roofline"] = {"bound": "hbm", "kernel": f"skinny_gemm_kernel<{'AWQ' if m.config.awq else 'dense'}, TT=1, R={dom['R']}> "
-                                                       f"gate_up N={dom['N']} K={dom['K']} T={eng.tree_size}",
+            import hashlib
+            with open(os.path.join(ROOT, "umbrella_amd", "csrc", "gemm.hip"), "rb") as f:
+                src_hash = hashlib.sha256(f.read()).hexdigest()[:16]
+            for pmc_name in ("r02_pmc_gemm70b_traffic.json", "r01_pmc_gemm70b_traffic.json"):
+                pmc = os.path.join(ROOT, "profiles", pmc_name)
+                if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
+                    with open(pmc) as f:
+                        rec = json.load(f)
+                    if rec.get("gemm_hip_sha256_16") in (None, src_hash):
+                        traffic = rec["gate_up_traffic_bytes"]
+                        tsrc = f"static: profiles/{pmc_name} (separate rocprofv3 --pmc passes" + \
+                               (", same gemm.hip)" if rec.get("gemm_hip_sha256_16") else ", kernel source hash not recorded)")
+                        break
+            out["roofline"] = {"bound": "hbm", "kernel": f"{dom['family']} {'int4' if m.config.awq else 'dense'} gate_up "
+                                                       f"N={dom['N']} K={dom['K']} T={eng.tree_size}",
                                "achieved": round(dom["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                                "avg_launch_us": round(dom["us"], 2), "bytes_per_launch": dom["bytes"],
-                               "layer_gemms": {k: {"us": round(v["us"], 2), "GBs": round(v["gbs"], 1), "R": v["R"], "S": v["S"]}
-                                               for k, v in kr.items()},
+                               "layer_gemms": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                                   if kk not in ("N", "K", "bytes")} for k, v in kr.items()},
                                "layer_gemms_GBs": round(tot_b / tot_us / 1e3, 1)}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 at N = 1 only
             try:
