@@ -64,6 +64,70 @@ def generate_sequoia_tree(width: int, depth: int, acc=None, json_file=None):
     return out
 
 
+def generate_budget_tree(size: int, max_depth: int, acc=None, json_file=None):
+    """Growmap with a node budget instead of a fixed width per level: the `size - 1` non-root nodes with the highest
+    path acceptance probability among all nodes of depth <= max_depth (rank-r child of a node multiplies the path by
+    acc[r]).  For a given budget this maximises the expected accept length under the rank-acceptance model, and the
+    levels get the widths the probabilities ask for (narrow near the root, where only len(acc) children exist, wide
+    where the mass is).  Depth is capped because every level costs one draft forward while the verify is flat in the
+    tree size on MI355X (scripts/tune_growmap.py).  Same JSON schema as generate_sequoia_tree: nodes are numbered level
+    by level, within a level by (parent order, rank) -- the order the engines place top-k children in."""
+    acc = list(DEFAULT_ACC if acc is None else acc)
+    assert size >= 1 and max_depth >= 1
+    # best-first expansion; heap entries: (-log p, tie-break counter, parent id, rank, depth)
+    nodes = [(-1, 0, 0)]                                  # (parent, rank, depth) in pick order; node 0 = root
+    heap, cnt = [], 0
+    def push_children(pid, logp, depth):
+        nonlocal cnt
+        if depth >= max_depth:
+            return
+        # only the rank-0 child is pushed; a node's rank-(r+1) sibling enters the heap when rank r is picked, so
+        # ranks are always taken in order (acc is non-increasing)
+        if acc[0] > 0:
+            heapq.heappush(heap, (-(logp + math.log(acc[0])), cnt, pid, 0, depth + 1, logp))
+            cnt += 1
+    push_children(0, 0.0, 0)
+    while len(nodes) < size and heap:
+        nlp, _, pid, rank, depth, plogp = heapq.heappop(heap)
+        nid = len(nodes)
+        nodes.append((pid, rank, depth))
+        push_children(nid, -nlp, depth)
+        if rank + 1 < len(acc) and acc[rank + 1] > 0:
+            heapq.heappush(heap, (-(plogp + math.log(acc[rank + 1])), cnt, pid, rank + 1, depth, plogp))
+            cnt += 1
+    # renumber level-major, within a level by (parent's new index, rank)
+    kids = {}
+    for nid, (pid, rank, depth) in enumerate(nodes):
+        if nid:
+            kids.setdefault(pid, []).append((rank, nid))
+    order, level = [0], [0]
+    levels = [[0]]
+    while True:
+        nxt = []
+        for old in level:
+            nxt += [nid for _, nid in sorted(kids.get(old, []))]
+        if not nxt:
+            break
+        levels.append(nxt)
+        order += nxt
+        level = nxt
+    new_id = {old: new for new, old in enumerate(order)}
+    n = len(order)
+    succ = [[] for _ in range(n)]
+    tdepth = [0] * n
+    for old in order:
+        succ[new_id[old]] = [new_id[c] for _, c in sorted(kids.get(old, []))]
+        tdepth[new_id[old]] = nodes[old][2]
+    roots = [[new_id[o] for o in lv] for lv in levels]
+    branches = [[len(succ[i]) for i in lv] for lv in roots]
+    out = {"roots": roots, "branches": branches, "Successors": succ, "mask": successor_list_to_mask(succ),
+           "depth": tdepth, "size": n}
+    if json_file is not None:
+        with open(json_file, "w") as f:
+            json.dump(out, f, indent=4)
+    return out
+
+
 def expected_accept_length(growmap: dict, acc) -> float:
     """E[#accepted tokens per verify] (root + bonus counted as in the engines' dec_len/steps)
     if the rank-r child of any node is accepted with probability acc[r]."""
