@@ -63,6 +63,13 @@ def build_engine(wl, device, dtype, max_length, seed, pp=None):
     from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
     if wl["tree"] == "3x4":
         gm, acc = generate_sequoia_tree(3, 4), DEFAULT_ACC
+    elif wl["tree"] == "mi355x-T16d3":
+        # growmap re-tuned for the measured MI355X cost ratios (scripts/tune_growmap.py, profiles/r02_growmap_tuning_*.json):
+        # the 15 most probable nodes of depth <= 3 under the same acceptance vector -- one draft forward fewer, a full
+        # 16-row token tile in the verify
+        import json as _json
+        with open(os.path.join(ROOT, "umbrella_amd", "trees", "mi355x_70b_awq_1b-T16d3.json")) as f:
+            gm, acc = _json.load(f), DEFAULT_ACC
     else:
         gm, acc = generate_sequoia_tree(5, 6, ACC_5x6), ACC_5x6
     eng = StaticSpeculationEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=gm,
@@ -226,6 +233,9 @@ def main():
     ap.add_argument("--workload", default="70b-awq+1b", choices=sorted(WORKLOADS))
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--max-length", type=int, default=2048)
+    ap.add_argument("--tree", default=None, choices=[None, "3x4", "5x6", "mi355x-T16d3"],
+                    help="growmap override (default: the workload's reference tree); mi355x-T16d3 = the re-tuned tree, a "
+                         "second line next to the headline, never the headline itself")
     ap.add_argument("--parallel", default="replicas", choices=["replicas", "pp"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -239,7 +249,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.tree:
+        wl["tree"] = args.tree
+        wl["desc"] = wl["desc"] + f" [growmap override: {args.tree}]"
     dtype = torch.float16 if wl["dtype"] == "fp16" else torch.bfloat16
 
     if args.parallel == "pp" and world > 1:

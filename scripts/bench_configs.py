@@ -48,4 +48,21 @@ if getattr(m, "_off", None) is not None:
     streamed = sum(1 for h in m.host_slabs if h is not None) * m.slab_bytes
     out["host_link_GBs"] = round(streamed * a.steps / dt / 1e9, 1)
     out["streamed_GB_per_verify"] = round(streamed / 1e9, 2)
+    out["cross_forward_prefetch"] = os.environ.get("UMB_OFFLOAD_PREFETCH", "1") != "0"
+    out["draft_in_graph"] = eng.graph_scope == "draft" and eng.use_graph
+    # the floor: the same slabs copied back to back on the side stream with nothing else running (pure link time)
+    torch.cuda.synchronize()
+    hs = [h for h in m.host_slabs if h is not None]
+    with torch.cuda.stream(m.load_stream):
+        for i, h in enumerate(hs[:4]):
+            m._dev_slabs[i & 1].copy_(h, non_blocking=True)
+    torch.cuda.synchronize(); t0 = time.time()
+    with torch.cuda.stream(m.load_stream):
+        for i, h in enumerate(hs):
+            m._dev_slabs[i & 1].copy_(h, non_blocking=True)
+    torch.cuda.synchronize(); t_stream = time.time() - t0
+    out["pure_stream_ms_per_verify"] = round(t_stream * 1e3, 2)
+    out["pure_stream_GBs"] = round(streamed / t_stream / 1e9, 1)
+    out["iter_over_stream"] = round(dt / a.steps / t_stream, 4)
+    m._pf_state[0] = m._pf_state[1] = -1        # the slabs were overwritten: the next forward must refetch
 print(json.dumps(out))

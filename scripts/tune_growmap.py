@@ -63,7 +63,9 @@ draft = AutoModelLM.from_pretrained(args.draft, max_length=2048, device=dev, dty
 draft.alloc(exit_layer=16)
 for m in (target, draft):
     m.prefill_tokens(torch.randint(3, 128000, (args.prefix,), dtype=torch.int32, device=dev), 0)
-verify = {T: graph_ms(target, T, args.prefix) for T in (1, 13, 17, 25, 31, 33, 41, 49, 57, 64)}
+# measured on both sides of every 16-row token-tile boundary: the cost steps there (MFMA work and activation traffic per
+# weight byte grow with the tile count), it is flat inside a tile
+verify = {T: graph_ms(target, T, args.prefix) for T in (1, 8, 13, 16, 17, 24, 32, 33, 48, 49, 64)}
 dforward = {w: graph_ms(draft, w, args.prefix) for w in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)}
 print("verify ms by T:", {k: round(v, 3) for k, v in verify.items()}, flush=True)
 print("draft forward ms by rows:", {k: round(v, 3) for k, v in dforward.items()}, flush=True)
@@ -101,7 +103,7 @@ for w in range(1, 17):                                   # the reference's gener
         t = t_draft + t_ver + args.fixed_ms
         rows.append(dict(kind="sequoia", w=w, d=d, T=T, accept=round(e, 3), draft_ms=round(t_draft, 3), verify_ms=round(t_ver, 3),
                          iter_ms=round(t, 3), tokens_s=round(e / t * 1e3, 1)))
-for T in range(8, args.max_tree + 1, 4):                 # node-budget trees: the T - 1 most probable nodes of depth <= d
+for T in list(range(6, 17)) + list(range(20, args.max_tree + 1, 4)):                 # node-budget trees: the T - 1 most probable nodes of depth <= d
     for d in range(2, 17):
         gm = generate_budget_tree(T, d, acc)
         if len(gm["roots"]) - 1 < d:

@@ -95,3 +95,34 @@ def test_wide_forward_split_rule():
     for T in range(65, 1100, 37):                                          # always within [1, plan]
         for N, S in plan.values():
             assert 1 <= lib.umb_gemm_wide_split(T, N, S) <= S
+
+
+def test_budget_tree_generator_and_shipped_mi355x_tree():
+    """generate_budget_tree: level-major numbering the engines rely on (children of a level laid out by parent order,
+    rank), monotone expected accept length in the node budget, the budget respected, and the shipped MI355X-tuned
+    growmap (scripts/tune_growmap.py) is its output for the reference's default acceptance vector."""
+    import json
+    import os
+    from umbrella_amd.sequoia_utils import DEFAULT_ACC, expected_accept_length, generate_budget_tree, generate_sequoia_tree
+    prev = 0.0
+    for T in (2, 5, 13, 16, 31, 64):
+        gm = generate_budget_tree(T, 6, DEFAULT_ACC)
+        assert gm["size"] == T == len(gm["Successors"]) == len(gm["depth"]) == len(gm["mask"])
+        cur = 1
+        for lv, ids in enumerate(gm["roots"]):
+            assert ids == list(range(ids[0], ids[0] + len(ids)))
+            for j, i in enumerate(ids):
+                b = gm["branches"][lv][j]
+                assert gm["Successors"][i] == list(range(cur, cur + b)) and gm["depth"][i] == lv
+                assert b <= len(DEFAULT_ACC)
+                cur += b
+        assert cur == T and max(gm["depth"]) <= 6
+        e = expected_accept_length(gm, DEFAULT_ACC)
+        assert e > prev
+        prev = e
+    # for the same budget and depth a budget tree is at least as good as the fixed-width Sequoia tree
+    assert expected_accept_length(generate_budget_tree(13, 4, DEFAULT_ACC), DEFAULT_ACC) >= \
+        expected_accept_length(generate_sequoia_tree(3, 4), DEFAULT_ACC)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "umbrella_amd", "trees", "mi355x_70b_awq_1b-T16d3.json")) as f:
+        assert json.load(f) == generate_budget_tree(16, 3, DEFAULT_ACC)
