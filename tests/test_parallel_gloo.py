@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from umbrella_amd.parallel import (OP_CHUNK, OP_COMMIT, OP_STOP, OP_TREE, PipelineComm, split_layers)
+from umbrella_amd.parallel import OP_DECODE, OP_PREFILL, OP_STOP, PipelineComm, split_layers
 
 
 def test_split_layers():
@@ -27,43 +27,63 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    """Stand-in stages (every stage adds 1 to the activations) driven through the real protocol: one plan word per mode
+    change, a prompt walked in fixed chunks, then the decode loop with the commit of iteration i broadcast together with
+    the continue flag once rank 0 knows what follows."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    H, Tmax, max_path = 16, 32, 5
+    H, Tmax, max_path, T = 16, 32, 5, 13
     comm = PipelineComm(rank, world, "cpu", H, torch.float32, Tmax, max_path)
     log = []
+    P, start, chunk = 7, 100, 4
     if rank == 0:
+        comm.plan(OP_PREFILL, P, start, 1, chunk)
+        for lo in range(0, P, chunk):
+            rows = min(P, lo + chunk) - lo
+            h = torch.full((rows, H), 10.0)
+            h[:, 0] = torch.arange(lo, lo + rows)
+            comm.send_activations(h + 1.0)                       # stage 0 "compute": +1
+        log.append(comm.return_ids(n=1).tolist())
+        comm.plan(OP_DECODE)
         for it in range(3):
-            T = 13 if it < 2 else 7
-            c = comm.command(OP_TREE if it < 2 else OP_CHUNK, T, 100 + it, 1)
+            if it:                                               # commit of the previous iteration + "one more follows"
+                comm.share_commit(torch.tensor([2, 9, 0, 50 + it - 1, 3, 0, 0, 0], dtype=torch.int32),
+                                  torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=1)
             h = torch.full((T, H), float(it + 1))
             h[:, 0] = torch.arange(T)
-            comm.send_activations(h + 1.0)                       # stage 0 "compute": +1
-            ids = comm.return_ids(n=(T if it < 2 else 1))
-            log.append(ids.tolist())
-            comm.command(OP_COMMIT)
-            res = torch.tensor([2, 9, 0, 50 + it, 3, 0, 0, 0], dtype=torch.int32)
-            comm.share_commit(res, torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32))
-        comm.command(OP_STOP)
+            comm.send_activations(h + 1.0)
+            log.append(comm.return_ids(n=T).tolist())
+        comm.share_commit(torch.tensor([2, 9, 0, 52, 3, 0, 0, 0], dtype=torch.int32),
+                          torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=0)
+        comm.plan(OP_STOP)
         q.put(("rank0", log))
     else:
+        own = torch.zeros(Tmax, H)                               # the "stage model's hidden buffer"
         while True:
-            c = comm.command()
+            c = comm.plan()
             if c[0] == OP_STOP:
                 break
-            if c[0] in (OP_TREE, OP_CHUNK):
-                T = c[1]
-                h = comm.recv_activations(T).clone()
-                h = h + 1.0                                      # every stage adds 1
-                comm.send_activations(h)
-                if comm.last:
-                    n = T if c[0] == OP_TREE else 1
-                    ids = (h[:, 0] + h[:, 1]).int()              # function of the fully processed activations
-                    comm.return_ids(ids, n)
-                log.append((c[0], T, c[2]))
-            elif c[0] == OP_COMMIT:
-                res, path = comm.share_commit()
-                log.append(("commit", res.tolist(), path.tolist()))
+            if c[0] == OP_PREFILL:
+                Pp, st, want, ch = c[1], c[2], c[3], c[4]
+                for lo in range(0, Pp, ch):
+                    rows = min(Pp, lo + ch) - lo
+                    h = comm.recv_activations(rows, into=own)
+                    assert h.data_ptr() == own.data_ptr()       # received in place, no staging copy
+                    h += 1.0
+                    comm.send_activations(h)
+                    if comm.last and want and lo + ch >= Pp:
+                        comm.return_ids((h[-1:, 0] + h[-1:, 1]).int(), 1)
+                    log.append(("chunk", rows, st + lo))
+            elif c[0] == OP_DECODE:
+                cont = 1
+                while cont:
+                    h = comm.recv_activations(T, into=own)
+                    h += 1.0
+                    comm.send_activations(h)
+                    if comm.last:
+                        comm.return_ids((h[:, 0] + h[:, 1]).int(), T)
+                    res, path, cont = comm.share_commit()
+                    log.append(("commit", res.tolist(), path.tolist(), cont))
         q.put((f"rank{rank}", log))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,13 +101,14 @@ def test_pipeline_protocol_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # after `world` stages each adding 1: h[:,0] = t + world, h[:,1] = it+1 + world
-    for it, ids in enumerate(got["rank0"]):
-        T = 13 if it < 2 else 7
-        exp = [t + world + (it + 1) + world for t in range(T)]
-        assert ids == (exp if it < 2 else exp[:1])
+    # after `world` stages each adding 1: h[:,0] = t + world, h[:,1] = fill + world
+    log0 = got["rank0"]
+    assert log0[0] == [6 + world + 10 + world]                   # last prompt row (index 6) after the chunked prefill
+    for it, ids in enumerate(log0[1:]):
+        assert ids == [t + world + (it + 1) + world for t in range(13)]
     for r in range(1, world):
         log = got[f"rank{r}"]
-        assert [e for e in log if e[0] != "commit"] == [(OP_TREE, 13, 100), (OP_TREE, 13, 101), (OP_CHUNK, 7, 102)]
+        assert [e for e in log if e[0] == "chunk"] == [("chunk", 4, 100), ("chunk", 3, 104)]
         commits = [e for e in log if e[0] == "commit"]
-        assert len(commits) == 3 and commits[1][1][:5] == [2, 9, 0, 51, 3] and commits[1][2] == [0, 2, 5, 0, 0]
+        assert [c[3] for c in commits] == [1, 1, 0]                # two "continue", then leave the decode loop
+        assert commits[1][1][:5] == [2, 9, 0, 51, 3] and commits[1][2] == [0, 2, 5, 0, 0]

@@ -9,18 +9,27 @@ so this buys capacity, not speed: per verify the [T, H] activation makes world-1
 stage returns the T sampled ids, and rank 0 broadcasts the accept result so every stage compacts its own
 KV slice.  Token ids are identical to the single-GPU result: same kernels, same order.
 
-Protocol (all from rank 0, one int64[8] control broadcast per forward):
-    [OP_TREE, T]                         tree-mode verify over the engine's tree tables
-    [OP_CHUNK, T, start, want_head]      causal chunk at slots/positions start.. (prefill / append)
-    [OP_COMMIT] + int32[8 + max_path]    accept result + path -> KV compaction, num_nodes update
-    [OP_RESET] / [OP_STOP]
+Protocol.  Stage ranks follow a fixed op schedule; rank 0 speaks only at mode changes:
+    plan  (int64[8] broadcast)  [OP_PREFILL, P, start, want_head]   every stage then walks the same ceil(P / chunk)
+                                                                    causal chunks: recv -> forward -> send
+                                [OP_DECODE]                         enter the decode loop
+                                [OP_RESET] / [OP_STOP]
+    decode loop, per iteration: recv [T, H] -> forward_tree (hipGraph) -> send; last stage: arg-max -> ids to rank 0;
+                                then ONE broadcast int32[8 + max_path] = accept result + path + `cont` flag:
+                                KV compaction, and cont = 0 leaves the loop (back to waiting for a plan).
+Rank 0 defers the commit of iteration i until it knows what follows (the next step(): cont = 1; reset / new
+prompt / shutdown: cont = 0), so the decode loop costs exactly one collective per iteration besides the hops, and a
+stage rank reads back one word per iteration (the flag).  Activations are received straight into the stage model's
+hidden buffer; prompt chunks travel in PREFILL_CHUNK-row messages.
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
-OP_STOP, OP_TREE, OP_CHUNK, OP_COMMIT, OP_RESET = 0, 1, 2, 3, 4
+OP_STOP, OP_DECODE, OP_PREFILL, OP_RESET = 0, 1, 2, 4
+OP_TREE, OP_CHUNK, OP_COMMIT = OP_DECODE, OP_PREFILL, 3          # legacy names
+COMMIT_CONT = 5                                                   # word of the commit message that carries `cont`
 
 
 def split_layers(num_layers: int, world: int):
@@ -35,14 +44,23 @@ def split_layers(num_layers: int, world: int):
 
 
 class PipelineComm:
-    """Control + activation plumbing, independent of what a stage computes (CPU-testable with gloo)."""
+    """Control + activation plumbing, independent of what a stage computes (CPU-testable with gloo).
+    host_staging: point-to-point payloads go through pinned host buffers (gloo moves CPU tensors only); used by the
+    two-process test that runs real HIP stages on one GPU.  With RCCL the device buffers are sent as they are."""
 
-    def __init__(self, rank: int, world: int, device, hidden: int, dtype, max_tokens: int, max_path: int):
+    def __init__(self, rank: int, world: int, device, hidden: int, dtype, max_tokens: int, max_path: int,
+                 host_staging: bool = False):
         self.rank, self.world, self.device = rank, world, device
-        self.ctrl = torch.zeros(8, dtype=torch.int64, device=device)
-        self.h = torch.zeros(max_tokens, hidden, dtype=dtype, device=device)
+        self.host_staging = host_staging and str(device) != "cpu"
+        cdev = "cpu" if self.host_staging else device
+        self.ctrl = torch.zeros(8, dtype=torch.int64, device=cdev)
         self.ids = torch.zeros(max_tokens, dtype=torch.int32, device=device)
-        self.commit = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=device)
+        self.commit = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=cdev)
+        self.commit_dev = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=device)
+        self.h = torch.zeros(max_tokens, hidden, dtype=dtype, device=device)      # only used when no model buffer is given
+        if self.host_staging:
+            self._h_host = torch.zeros(max_tokens, hidden, dtype=dtype).pin_memory()
+            self._ids_host = torch.zeros(max_tokens, dtype=torch.int32).pin_memory()
 
     @property
     def first(self):
@@ -52,41 +70,68 @@ class PipelineComm:
     def last(self):
         return self.rank == self.world - 1
 
-    def command(self, *vals):
-        """rank 0: broadcast a control word; other ranks: receive it.  Returns the list of ints."""
+    def plan(self, *vals):
+        """rank 0: broadcast a plan word; other ranks: receive it.  Returns the list of ints."""
         if self.first:
             self.ctrl.zero_()
             self.ctrl[:len(vals)] = torch.tensor(vals, dtype=torch.int64)
         dist.broadcast(self.ctrl, src=0)
         return self.ctrl.tolist()
 
-    def recv_activations(self, T):
+    command = plan                                                # legacy name
+
+    def _recv(self, buf, host, src):
+        if self.host_staging:
+            dist.recv(host[:buf.shape[0]], src=src)
+            buf.copy_(host[:buf.shape[0]], non_blocking=True)
+        else:
+            dist.recv(buf, src=src)
+
+    def _send(self, buf, host, dst):
+        if self.host_staging:
+            host[:buf.shape[0]].copy_(buf)                        # synchronises with the producing kernels
+            dist.send(host[:buf.shape[0]], dst=dst)
+        else:
+            dist.send(buf, dst=dst)
+
+    def recv_activations(self, T, into=None):
+        """ranks > 0: the previous stage's [T, H] rows, received straight into `into` (the stage model's hidden buffer)."""
+        buf = (self.h if into is None else into)[:T]
         if not self.first:
-            dist.recv(self.h[:T], src=self.rank - 1)
-        return self.h[:T]
+            self._recv(buf, getattr(self, "_h_host", None), self.rank - 1)
+        return buf
 
     def send_activations(self, h):
         if not self.last:
-            dist.send(h.contiguous(), dst=self.rank + 1)
+            self._send(h if h.is_contiguous() else h.contiguous(), getattr(self, "_h_host", None), self.rank + 1)
 
     def return_ids(self, ids=None, n=1):
         """last stage -> rank 0 (no-op when they coincide)."""
         if self.world == 1:
             return ids
         if self.last:
-            dist.send(ids[:n].contiguous(), dst=0)
+            self._send(ids[:n].contiguous(), getattr(self, "_ids_host", None), 0)
             return ids
         if self.first:
-            dist.recv(self.ids[:n], src=self.world - 1)
+            self._recv(self.ids[:n], getattr(self, "_ids_host", None), self.world - 1)
             return self.ids[:n]
         return None
 
-    def share_commit(self, res=None, path=None):
+    def share_commit(self, res=None, path=None, cont=1):
+        """rank 0: accept result (int32[8]) + path + continue flag -> every stage.  Returns (res, path, cont) views of
+        the device copy (what the compaction kernel reads)."""
         if self.first:
-            self.commit[:8] = res[:8]
-            self.commit[8:8 + path.numel()] = path
-        dist.broadcast(self.commit, src=0)
-        return self.commit[:8], self.commit[8:]
+            self.commit_dev[:8] = res[:8]
+            self.commit_dev[8:8 + path.numel()] = path
+            self.commit_dev[COMMIT_CONT] = cont
+            if self.host_staging:
+                self.commit.copy_(self.commit_dev)
+        src = self.commit if self.host_staging else self.commit_dev
+        dist.broadcast(src, src=0)
+        if self.host_staging and not self.first:
+            self.commit_dev.copy_(self.commit)
+        flag = int(src[COMMIT_CONT]) if not self.first else cont
+        return self.commit_dev[:8], self.commit_dev[8:], flag
 
 
 class PipelinedTarget:
@@ -97,23 +142,33 @@ class PipelinedTarget:
         self.m, self.comm, self.eng = stage_model, comm, engine
         self.config, self.max_length, self.eos_tokens = stage_model.config, stage_model.max_length, stage_model.eos_tokens
         self.kv_cache, self.CHUNK, self.num_layers = stage_model.kv_cache, stage_model.CHUNK, stage_model.num_layers
-        self.PREFILL_CHUNK = self.CHUNK          # activations travel in CHUNK-row messages (PipelineComm buffers)
+        self.PREFILL_CHUNK = stage_model.PREFILL_CHUNK
         self._off = None
+        self._tree_graph = None
 
     def reserve(self, tokens, logit_rows=None):
         self.m.reserve(tokens, logit_rows)
 
     def clear(self):
-        self.comm.command(OP_RESET)
+        self.eng._leave_decode()
+        self.comm.plan(OP_RESET)
         self.m.clear()
 
     def weight_bytes(self):
         return self.m.weight_bytes()
 
+    def _stage0_tree(self, tokens_all, n_dev, depth, T, mask_bits, mask_words):
+        """stage 0's share of the verify, replayed as a hipGraph (all run-time state is read from device memory)."""
+        run = lambda: self.m.forward_tree(tokens_all, n_dev, depth, 0, T, mask_bits, mask_words, head_from=0)
+        if not self.eng.use_graph:
+            return run()
+        if self._tree_graph is None:
+            self._tree_graph = _capture(run, self.m.device)
+        self._tree_graph.replay()
+
     # tree-mode verify: returns sampled ids [T] on rank 0
     def verify_tree(self, tokens_all, n_dev, depth, T, mask_bits, mask_words):
-        self.comm.command(OP_TREE, T)
-        self.m.forward_tree(tokens_all, n_dev, depth, 0, T, mask_bits, mask_words, head_from=0)
+        self._stage0_tree(tokens_all, n_dev, depth, T, mask_bits, mask_words)
         self.comm.send_activations(self.m.hidden_buffer[:T])
         return self.comm.return_ids(n=T)
 
@@ -121,18 +176,19 @@ class PipelinedTarget:
     def prefill_tokens(self, ids, start, want_logits=True):
         P = ids.shape[0]
         out = None
-        for lo in range(0, P, self.CHUNK):
-            hi = min(P, lo + self.CHUNK)
+        self.eng._leave_decode()
+        chunk = prefill_chunk(self.m)
+        self.comm.plan(OP_PREFILL, P, start, int(want_logits), chunk)
+        for lo in range(0, P, chunk):
+            hi = min(P, lo + chunk)
             T = hi - lo
             last = hi == P and want_logits
-            self.comm.command(OP_CHUNK, T, start + lo, int(last))
             pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=self.m.device)
             pre = torch.tensor([start + lo], dtype=torch.int32, device=self.m.device)
             local_head = last and self.m.is_last            # single-stage group: the head is here
             self.m.forward_explicit(ids[lo:hi].contiguous(), pos, pos, pre, head_from=(T - 1 if local_head else T))
             self.comm.send_activations(self.m.hidden_buffer[:T])
             if local_head:
-                from . import _lib
                 out = self.eng._first_token(self.m.logits_buffer[0]).clone()
             elif last:
                 out = self.comm.return_ids(n=1)
@@ -140,51 +196,86 @@ class PipelinedTarget:
         return out
 
 
-def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False):
-    """Event loop of ranks > 0.  `tables` = dict(depth, mask_bits, mask_words, n_dev, eos_dev, n_eos, max_path)."""
+def prefill_chunk(model) -> int:
+    """rows per prompt message: the stage model's prompt chunk (1024 when the workspace allows)"""
+    return max(model.CHUNK, min(model.PREFILL_CHUNK, model.ws_tokens))
+
+
+def _capture(run, device):
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()                                              # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    torch.cuda.synchronize()
+    return g
+
+
+def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False, use_graph=True):
+    """Event loop of ranks > 0.  `tables` = dict(depth, mask_bits, mask_words, n_dev, eos_dev, n_eos, max_path, tree_size)."""
     from . import _lib
     dev = model.device
     sampled = torch.zeros(comm.ids.shape[0], dtype=torch.int32, device=dev)
     dummy_tokens = torch.zeros(model.max_length + comm.ids.shape[0] + 8, dtype=torch.int32, device=dev)
     n_dev = tables["n_dev"]
     V = model.config.vocab_size
+    T = tables["tree_size"]
+    tree_graph = None
+
+    def tree_forward():
+        model.forward_tree(dummy_tokens, n_dev, tables["depth"], 0, T, tables["mask_bits"], tables["mask_words"], head_from=0)
+        if comm.last:
+            _lib.call("umb_argmax_rows", sampled, model.logits_buffer, T, V)
+
     while True:
-        c = comm.command()
+        c = comm.plan()
         op = c[0]
         if op == OP_STOP:
             return
         if op == OP_RESET:
             model.clear()
             n_dev.zero_()
-        elif op == OP_TREE:
-            T = c[1]
-            comm.recv_activations(T)
-            model.hidden_buffer[:T].copy_(comm.h[:T])
-            model.forward_tree(dummy_tokens, n_dev, tables["depth"], 0, T, tables["mask_bits"], tables["mask_words"],
-                               head_from=0)
-            comm.send_activations(model.hidden_buffer[:T])
-            if comm.last:
-                _lib.call("umb_argmax_rows", sampled, model.logits_buffer, T, V)
-                comm.return_ids(sampled, T)
-        elif op == OP_CHUNK:
-            T, start, want = c[1], c[2], c[3]
-            comm.recv_activations(T)
-            model.hidden_buffer[:T].copy_(comm.h[:T])
-            pos = torch.arange(start, start + T, dtype=torch.int32, device=dev)
-            pre = torch.tensor([start], dtype=torch.int32, device=dev)
-            model.forward_explicit(dummy_tokens[:T], pos, pos, pre, head_from=(T - 1 if want else T))
-            comm.send_activations(model.hidden_buffer[:T])
-            if comm.last and want:
-                row = model.logits_buffer[0]
-                if mask_first_eos and tables["n_eos"]:
-                    _lib.call("umb_mask_eos", row, tables["eos_dev"], tables["n_eos"])
-                _lib.call("umb_argmax_rows", sampled[:1], row, 1, V)
-                comm.return_ids(sampled, 1)
-            n_dev.fill_(start + T)
-        elif op == OP_COMMIT:
-            res, path = comm.share_commit()
-            model.kv_cache.compact(res, path.contiguous(), tables["max_path"])
-            n_dev.copy_(res[3:4])
+        elif op == OP_PREFILL:
+            P, start, want, chunk = c[1], c[2], c[3], c[4]
+            for lo in range(0, P, chunk):
+                hi = min(P, lo + chunk)
+                rows = hi - lo
+                last = hi == P and want
+                comm.recv_activations(rows, into=model.hidden_buffer)
+                pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=dev)
+                pre = torch.tensor([start + lo], dtype=torch.int32, device=dev)
+                model.forward_explicit(dummy_tokens[:rows], pos, pos, pre, head_from=(rows - 1 if last else rows))
+                comm.send_activations(model.hidden_buffer[:rows])
+                if comm.last and last:
+                    row = model.logits_buffer[0]
+                    if mask_first_eos and tables["n_eos"]:
+                        _lib.call("umb_mask_eos", row, tables["eos_dev"], tables["n_eos"])
+                    _lib.call("umb_argmax_rows", sampled[:1], row, 1, V)
+                    comm.return_ids(sampled, 1)
+            n_dev.fill_(start + P)
+        elif op == OP_DECODE:
+            cont = 1
+            while cont:
+                comm.recv_activations(T, into=model.hidden_buffer)
+                if use_graph:
+                    if tree_graph is None:
+                        torch.cuda.current_stream().synchronize()
+                        keep = model.hidden_buffer[:T].clone()
+                        tree_graph = _capture(tree_forward, dev)
+                        model.hidden_buffer[:T].copy_(keep)         # the warm-up pass overwrote the received rows
+                    tree_graph.replay()
+                else:
+                    tree_forward()
+                comm.send_activations(model.hidden_buffer[:T])
+                if comm.last:
+                    comm.return_ids(sampled, T)
+                res, path, cont = comm.share_commit()
+                model.kv_cache.compact(res, path.contiguous(), tables["max_path"])
+                n_dev.copy_(res[3:4])
 
 
 def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **config):
@@ -213,20 +304,22 @@ def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **co
     stage = Llama(target, max_length=max_length, device=device, dtype=dtype, seed=seed)
     stage.alloc(layer_range=(lo, hi))
     T, depth_levels = gm["size"], len(gm["roots"])
-    stage.reserve(max(stage.CHUNK, T))
-    comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.CHUNK, T), depth_levels)
+    stage.reserve(max(stage.PREFILL_CHUNK, T), logit_rows=max(stage.CHUNK, T))
+    host_staging = dist.get_backend() == "gloo"
+    comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.PREFILL_CHUNK, T), depth_levels,
+                        host_staging=host_staging)
     if rank != 0:
         tables = dict(depth=torch.tensor(gm["depth"], dtype=torch.int32, device=device),
                       mask_bits=pack_mask_bits((torch.tensor(gm["mask"]) == 1).to(device)).contiguous(),
                       n_dev=torch.zeros(1, dtype=torch.int32, device=device),
                       eos_dev=torch.tensor(list(cfg.eos_token_id), dtype=torch.int32, device=device),
-                      n_eos=len(cfg.eos_token_id), max_path=depth_levels)
+                      n_eos=len(cfg.eos_token_id), max_path=depth_levels, tree_size=T)
         tables["mask_words"] = tables["mask_bits"].shape[1]
-        stage_worker(stage, comm, tables)
+        stage_worker(stage, comm, tables, use_graph=config.get("hip_graph", True))
         return None
     for k in ("offload", "cuda_graph", "num_cache_layers"):      # single-GPU placement knobs of the reference
         config.pop(k, None)
-    eng = PipelinedStaticEngine(draft, target, dtype=dtype, device=device, growmap=gm, seed=seed, hip_graph=False,
+    eng = PipelinedStaticEngine(draft, target, dtype=dtype, device=device, growmap=gm, seed=seed,
                                 stage_model=stage, comm=comm, **config)
     eng.initialize()
     return eng
@@ -234,7 +327,8 @@ def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **co
 
 def shutdown_pipeline(eng):
     """Rank 0: release the stage workers blocked in build_pipelined_engine."""
-    eng._comm.command(OP_STOP)
+    eng._leave_decode()
+    eng._comm.plan(OP_STOP)
 
 
 def run_pp_bench(args, wl, dtype, device, rank, world):
@@ -281,17 +375,19 @@ from .speculation.static_speculation_engine import StaticSpeculationEngine as _S
 
 
 class PipelinedStaticEngine(_Static):
-    """Static engine whose target is a PipelinedTarget (rank 0 of a layer-sharded group)."""
+    """Static engine whose target is a PipelinedTarget (rank 0 of a layer-sharded group).  The draft tree replays as a
+    hipGraph, stage 0's share of the verify as another; hops, accept scan and the commit broadcast are eager."""
 
     def __init__(self, *a, stage_model=None, comm=None, **kw):
-        kw["hip_graph"] = False                     # cross-rank hops are launched eagerly
         super().__init__(*a, **kw)
         self._stage_model, self._comm = stage_model, comm
+        self._in_decode, self._pending = False, False
 
     def initialize(self):
         self._require_greedy()
         self._target_model = PipelinedTarget(self._stage_model, self._comm, self)
         super().initialize()
+        self.graph_scope = "draft"                   # cross-rank hops cannot live inside the graph
 
     def _require_greedy(self):
         """The last stage returns arg-max token ids (T ints per verify) instead of [T, V] logits; sampling settings
@@ -304,6 +400,31 @@ class PipelinedStaticEngine(_Static):
         super().update_generation_args(**generation_args)
         self._require_greedy()
 
+    # ---- decode-mode bookkeeping: the commit of iteration i travels when rank 0 knows what follows it
+    def _flush_commit(self, cont):
+        if self._pending:
+            self._comm.share_commit(self.res, self.path, cont=cont)
+            self._pending = False
+
+    def _enter_decode(self):
+        if not self._in_decode:
+            self._comm.plan(OP_DECODE)
+            self._in_decode = True
+        else:
+            self._flush_commit(cont=1)
+
+    def _leave_decode(self):
+        if self._in_decode:
+            if self._pending:
+                self._flush_commit(cont=0)
+            else:                                    # decode mode entered but no iteration ran: cannot happen via step()
+                raise RuntimeError("pipeline left decode mode without a pending commit")
+            self._in_decode = False
+
+    def reset(self):
+        self._leave_decode()
+        super().reset()
+
     def _feed(self, lo, hi):
         ids = self.tokens[lo:hi]
         dlo = lo - 1 if (self.lookback and lo > 0) else lo          # see HipEngine._feed
@@ -315,13 +436,13 @@ class PipelinedStaticEngine(_Static):
         self.last_bonus = None
 
     def _verify_forward(self):
+        self._enter_decode()
         ids = self.target_model.verify_tree(self.tokens, self.n_dev, self.depth, self.tree_size, self.mask_bits,
                                             self.mask_words)
         self._remote_sampled = ids
 
-    def _iteration_launch(self):
+    def _iteration_tail(self):
         from . import _lib
-        self.build_tree()
         self._verify_forward()
         if self._comm.world > 1:
             self.sampled.copy_(self._remote_sampled)
@@ -329,8 +450,7 @@ class PipelinedStaticEngine(_Static):
             _lib.call("umb_argmax_rows", self.sampled, self._stage_model.logits_buffer, self.tree_size, self.vocab_size)
         _lib.call("umb_accept_scan", self.sampled, self.parents, self.tokens, self.n_dev, self.tree_size,
                   self.eos_dev, len(self.eos_tokens), self.res, self.path)
-        self._comm.command(OP_COMMIT)
-        res, path = self._comm.share_commit(self.res, self.path)
+        self._pending = True                          # broadcast with the next iteration's `cont` (or on leaving)
         self.draft_model.kv_cache.compact(self.res, self.path, self.max_path)
         self._stage_model.kv_cache.compact(self.res, self.path, self.max_path)
         self.res_host.copy_(self.res, non_blocking=True)
