@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--tree", default=None, choices=[None, "3x4", "5x6", "mi355x-T16d3"],
                     help="growmap override (default: the workload's reference tree); mi355x-T16d3 = the re-tuned tree, a "
                          "second line next to the headline, never the headline itself")
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "pp"])
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "pp", "tp"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -258,6 +258,13 @@ def main():
     if args.parallel == "pp" and world > 1:
         from umbrella_amd.parallel import run_pp_bench
         return run_pp_bench(args, wl, dtype, device, rank, world)
+    if args.parallel == "tp":
+        if world == 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
+        from umbrella_amd.tensor_parallel import run_tp_bench
+        return run_tp_bench(args, wl, dtype, device, rank, world)
 
     import __graft_entry__ as ge
     ge.build()

@@ -48,52 +48,84 @@ def local_config(cfg: LlamaCfg, world: int) -> LlamaCfg:
     return c
 
 
-def _cols(t, lo, hi, packed):            # output-feature (N) slice of an HF [N, K] weight or an AWQ [K, N(/8)] tensor
-    return t[:, lo // 8:hi // 8] if packed == 8 else (t[:, lo:hi] if packed == 1 else t[lo:hi])
-
-
-def shard_state_dict(sd: dict, cfg: LlamaCfg, rank: int, world: int) -> dict:
-    """This rank's slice of an HF-named state dict (dense ``.weight`` [N, K], or AutoAWQ ``.qweight`` [K, N/8] /
+def shard_tensor(name: str, t: torch.Tensor, cfg: LlamaCfg, rank: int, world: int):
+    """This rank's slice of one HF-named tensor (dense ``.weight`` [N, K], or AutoAWQ ``.qweight`` [K, N/8] /
     ``.qzeros`` [K/G, N/8] / ``.scales`` [K/G, N]).  Column-split linears keep their K, row-split ones their N."""
     D, G = cfg.head_dim, cfg.awq_group
     q0, q1 = (x * D for x in shard_range(cfg.num_attention_heads, rank, world))
     k0, k1 = (x * D for x in shard_range(cfg.num_key_value_heads, rank, world))
     i0, i1 = shard_range(cfg.intermediate_size, rank, world)
     v0, v1 = shard_range(cfg.vocab_size, rank, world)
-    out = {}
     col = {"self_attn.q_proj": (q0, q1), "self_attn.k_proj": (k0, k1), "self_attn.v_proj": (k0, k1),
            "mlp.gate_proj": (i0, i1), "mlp.up_proj": (i0, i1)}
     row = {"self_attn.o_proj": (q0, q1), "mlp.down_proj": (i0, i1)}
-    for name, t in sd.items():
-        base, _, leaf = name.rpartition(".")
-        lin = next((l for l in list(col) + list(row) if base.endswith(l)), None)
-        if name == "lm_head.weight":
-            out[name] = t[v0:v1]
-        elif name == "model.embed_tokens.weight" and cfg.tie_word_embeddings:
-            out[name] = t
-            out["lm_head.weight"] = t[v0:v1]
-        elif lin in col:
-            lo, hi = col[lin]
-            if leaf == "weight":
-                out[name] = t[lo:hi]
-            elif leaf == "bias":
-                out[name] = t[lo:hi]
-            elif leaf in ("qweight", "qzeros"):
-                out[name] = t[:, lo // 8:hi // 8]
-            else:                                         # scales
-                out[name] = t[:, lo:hi]
-        elif lin in row:
-            lo, hi = row[lin]
-            if leaf == "weight":
-                out[name] = t[:, lo:hi]
-            elif leaf == "qweight":
-                out[name] = t[lo:hi]
-            else:                                         # qzeros / scales: one row per group of G input features
-                assert lo % G == 0 and hi % G == 0
-                out[name] = t[lo // G:hi // G]
-        else:
-            out[name] = t
+    base, _, leaf = name.rpartition(".")
+    lin = next((l for l in list(col) + list(row) if base.endswith(l)), None)
+    if name == "lm_head.weight":
+        return t[v0:v1]
+    if lin in col:
+        lo, hi = col[lin]
+        if leaf in ("weight", "bias"):
+            return t[lo:hi]
+        return t[:, lo // 8:hi // 8] if leaf in ("qweight", "qzeros") else t[:, lo:hi]
+    if lin in row:
+        lo, hi = row[lin]
+        if leaf == "weight":
+            return t[:, lo:hi]
+        if leaf == "qweight":
+            return t[lo:hi]
+        assert lo % G == 0 and hi % G == 0                 # qzeros / scales: one row per group of G input features
+        return t[lo // G:hi // G]
+    return t
+
+
+def shard_state_dict(sd: dict, cfg: LlamaCfg, rank: int, world: int) -> dict:
+    """shard_tensor over a whole state dict; tied embeddings get an explicit lm_head slice (the table stays whole)."""
+    out = {name: shard_tensor(name, t, cfg, rank, world) for name, t in sd.items()}
+    if cfg.tie_word_embeddings and "lm_head.weight" not in sd:
+        out["lm_head.weight"] = shard_tensor("lm_head.weight", sd["model.embed_tokens.weight"], cfg, rank, world)
     return {k: v.contiguous() for k, v in out.items()}
+
+
+class LazySyntheticShard:
+    """Mapping name -> this rank's slice of a seeded synthetic checkpoint, generated tensor by tensor on the device
+    (a 70B-AWQ state dict does not fit host RAM twice over).  Every rank draws the same full tensor from a generator
+    seeded by (seed, name), so the shards of all ranks are slices of one consistent model."""
+
+    def __init__(self, cfg: LlamaCfg, rank: int, world: int, device, dtype, seed: int = 0):
+        self.cfg, self.rank, self.world, self.device, self.dtype, self.seed = cfg, rank, world, device, dtype, seed
+
+    def _full(self, name):
+        import math
+        import zlib
+        from .models.synthetic import synth_tensor
+        cfg = self.cfg
+        gen = torch.Generator(device=self.device).manual_seed((self.seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31 - 1))
+        H, V = cfg.hidden_size, cfg.vocab_size
+        if name in ("model.embed_tokens.weight", "lm_head.weight"):
+            return synth_tensor((V, H), 1.0 if name.startswith("model.embed") else 0.05, self.dtype, self.device, gen)
+        if name.endswith("layernorm.weight") or name == "model.norm.weight":
+            return torch.ones(H, dtype=self.dtype, device=self.device)
+        base, _, leaf = name.rpartition(".")
+        lin = next(l for l in linear_shapes(cfg) if base.endswith(l))
+        n, k = linear_shapes(cfg)[lin]
+        std = 0.02 / (math.sqrt(2.0 * cfg.num_hidden_layers) if lin in ("self_attn.o_proj", "mlp.down_proj") else 1.0)
+        if leaf == "weight":
+            return synth_tensor((n, k), std, self.dtype, self.device, gen)
+        if leaf == "bias":
+            return synth_tensor((n,), 0.1, self.dtype, self.device, gen)
+        # AWQ triple: one generator stream per linear, so the three tensors are consistent whichever is asked for first
+        from .models.synthetic import synth_awq_tensors
+        g2 = torch.Generator(device=self.device).manual_seed((self.seed * 1000003 + zlib.crc32(base.encode())) % (2 ** 31 - 1))
+        qw, qz, sc = synth_awq_tensors(n, k, cfg.awq_group, self.device, g2, std)
+        return {"qweight": qw, "qzeros": qz, "scales": sc}[leaf]
+
+    def __getitem__(self, name):
+        if name == "model.embed_tokens.weight":
+            return self._full(name)
+        src = "model.embed_tokens.weight" if (name == "lm_head.weight" and self.cfg.tie_word_embeddings) else name
+        t = self._full(src)
+        return shard_tensor(name, t, self.cfg, self.rank, self.world).contiguous()
 
 
 # ------------------------------------------------------------------ communicators
@@ -172,11 +204,14 @@ class TensorParallelLlama:
         lc = local_config(cfg, world)
         shards = []
         for r in (ranks if ranks is not None else [comm.rank]):
-            sd = shard_state_dict(state_dict, cfg, r, world)
-            sd = dict(sd)
-            sd["model.embed_tokens.weight"] = state_dict["model.embed_tokens.weight"][:lc.vocab_size]   # placeholder: the
-            m = Llama(f"{name}-shard{r}", max_length=max_length, device=device, dtype=dtype, state_dict=sd, config=lc)   # table
-            m.alloc()                                                                                  # lives in `embed`
+            if isinstance(state_dict, dict):
+                sd = dict(shard_state_dict(state_dict, cfg, r, world))
+            else:                                           # lazy per-rank mapping (LazySyntheticShard): already sliced
+                assert ranks is None or len(ranks) == 1
+                sd = state_dict
+            m = Llama(f"{name}-shard{r}", max_length=max_length, device=device, dtype=dtype,
+                      state_dict=_EmbedPlaceholder(sd, lc.vocab_size), config=lc)
+            m.alloc()
             shards.append(m)
         embed = state_dict["model.embed_tokens.weight"].to(device=device, dtype=dtype)
         return cls(cfg, shards, embed, comm)
@@ -284,6 +319,18 @@ class TensorParallelLlama:
     _first_eos = None
 
 
+class _EmbedPlaceholder:
+    """what a shard's `Llama` sees: its slice of everything, and a V/P-row stand-in for the embedding table (the real,
+    replicated table lives in TensorParallelLlama.embed; the shard never embeds)"""
+
+    def __init__(self, sd, rows):
+        self.sd, self.rows = sd, rows
+
+    def __getitem__(self, name):
+        t = self.sd[name]
+        return t[:self.rows] if name == "model.embed_tokens.weight" else t
+
+
 class _ShardedKV:
     def __init__(self, caches):
         self.caches = caches
@@ -333,3 +380,58 @@ class TensorParallelStaticEngine(_Static):
 
     def _sample(self, dbg=None):
         self.sampled.copy_(self.target_model.sampled_ids[:self.tree_size])
+
+
+def run_tp_bench(args, wl, dtype, device, rank, world):
+    """bench.py --parallel tp: ONE request, every layer of the target split over the ranks (static tree, greedy).
+    SPMD -- all ranks run this function; rank 0 prints the JSON line.  Unmeasured on this project's single-GPU boxes."""
+    import json
+    import time
+
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    from .models.auto_model import AutoModelLM
+    from .models.config import KNOWN
+    from .sequoia_utils import generate_sequoia_tree
+    ge.build()
+    cfg = KNOWN[wl["target"]]
+    comm = DistComm()
+    tp = TensorParallelLlama.build(cfg, LazySyntheticShard(cfg, rank, world, device, dtype, seed=args.seed), world, comm,
+                                   args.max_length, device, dtype, name=wl["target"])
+    draft = AutoModelLM.from_pretrained(wl["draft"], max_length=args.max_length, device=device, dtype=dtype, cuda_graph=True)
+    draft.alloc(exit_layer=16)
+    eng = TensorParallelStaticEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=generate_sequoia_tree(3, 4),
+                                     max_length=args.max_length, draft_model_obj=draft, tp_target=tp, seed=args.seed)
+    eng.initialize()
+    g = torch.Generator().manual_seed(1234)
+    prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)
+    assert eng._prefill(prompt)
+    for _ in range(args.warmup):
+        eng.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    start = eng.num_nodes
+    t0 = time.time()
+    for _ in range(args.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    tokens = eng.num_nodes - start
+    out = None
+    if rank == 0:
+        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
+               "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
+               "config": {"workload": wl["desc"], "parallelism": f"tp{world}: heads / MLP width / vocabulary split, "
+                          "2 RCCL all-reduces of [T, H] fp32 per layer", "tree": "3x4", "prompt_len": args.prompt_len},
+               "accept_len": round(tokens / args.steps, 3)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
