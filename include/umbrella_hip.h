@@ -104,6 +104,10 @@ void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int* WK_out, in
 int umb_ll_token_tiles(int T);                  /* 1, 2 or 4 for T = 1..64; 0 otherwise */
 int umb_to_fm(void* out_fm, const void* x, int T, int K, int dtype, umb_stream_t stream);      /* row-major -> FM */
 int umb_from_fm(void* out, const void* x_fm, int T, int K, int dtype, umb_stream_t stream);
+/* measurement probe (bench.py / scripts): one read-only pass over `bytes` (multiple of 16) of device memory with
+ * 16-byte non-temporal loads -- the streaming rate the device delivers to a kernel; sink: 4 writable device bytes.
+ * No reference counterpart. */
+int umb_stream_read(const void* p, size_t bytes, void* sink, umb_stream_t stream);
 /* umb_embed_prep for the low-latency schedule: h row-major, hw = h * norm_w in FM layout, ssq[t][0..4); tokens /
  * positions / slots are clamped into [0, V) / [0, Lmax) (a tree that overruns the context cannot write past the caches) */
 int umb_embed_ll(void* h, const void* table, int H, int V, int Lmax, int T, const int* tok, const int* pos,
@@ -128,6 +132,12 @@ int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int
 int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
                         const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
                         void* vt_cache, int paired, const void* bias, int dtype, umb_stream_t stream);
+/* the same with the per-token 1/rms of the low-latency schedule applied to the reduced outputs (the GEMM ran on h * w):
+ * inv[t] = rsqrt(sum_{g < ssq_groups} ssq_in[t * ssq_stride + g] / ssq_dim + eps); ssq_in == NULL: umb_reduce_qkv_rope */
+int umb_reduce_qkv_rope2(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax, const int* pos,
+                         const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
+                         void* vt_cache, int paired, const void* bias, const float* ssq_in, int ssq_groups,
+                         int ssq_stride, float ssq_dim, float eps, int dtype, umb_stream_t stream);
 /* F.embedding (llama.py:124) + per-forward position/slot/prefix resolution.
  * explicit mode: tok/pos/slot/prefix given.  tree mode (tokens_all != NULL):
  * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i.

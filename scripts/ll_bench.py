@@ -42,6 +42,8 @@ def bench_shapes(model):
     dt = _lib.dtype_code(dtype)
     tot = [0.0, 0.0, 0.0]
     for name, N, K, awq, il in shapes:
+        if os.environ.get("ONLY") and name not in os.environ["ONLY"].split(","):
+            continue
         per = N * K // 2 + (N // 16) * (K // 128) * 64 if awq else N * K * 2
         ncopy = max(2, int(700e6 // per) + 1)
         lins = []
@@ -65,9 +67,11 @@ def bench_shapes(model):
             if ln.S > cap and (N // (64 * ln.R)) * cap >= 256:
                 S_eff = cap
 
+        R_old = int(os.environ.get("R_OLD", ln.R))
+
         def old(i):
             l = lins[i % ncopy]
-            _lib.call("umb_gemm", part, x, K, l.w, l.meta, T, N, K, l.awq, S_eff if epi_old == 0 else l.S, l.R, epi_old, dt)
+            _lib.call("umb_gemm", part, x, K, l.w, l.meta, T, N, K, l.awq, S_eff if epi_old == 0 else l.S, R_old, epi_old, dt)
             if name in ("o", "down"):
                 _lib.call("umb_reduce_residual_norm", part, S_eff, T, N, h, h, xn, nw, 1e-5, dt)
 
@@ -134,8 +138,25 @@ def bench_forward(name, layers, T, dtype):
           f"-> {wb/res['ll']/1e6:.0f} GB/s (ll)", flush=True)
 
 
+def bench_stream():
+    """read-only streaming rate of this box (umb_stream_read): one 2 GiB pass, and gate/up-sized (235 MB) launches
+    rotated over 4 regions so each launch misses the 256 MB Infinity Cache like a layer's weights do"""
+    buf = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+    buf.random_(0, 255)
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    us = timeit(lambda i: _lib.call("umb_stream_read", buf, buf.numel(), sink), reps=10, warm=2)
+    print(f"stream read 2 GiB: {us:.1f} us -> {buf.numel()/us/1e3:.0f} GB/s", flush=True)
+    for mb in (33, 67, 235, 470):
+        n = mb * 1000 * 1000 // 16 * 16
+        k = min(buf.numel() // n, 8)
+        us = timeit(lambda i: _lib.call("umb_stream_read", buf[(i % k) * n:], n, sink), reps=40, warm=4)
+        print(f"stream read {mb} MB launches (rotating {k} regions): {us:.1f} us -> {n/us/1e3:.0f} GB/s", flush=True)
+
+
 for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
-    if what in SHAPES:
+    if what == "stream":
+        bench_stream()
+    elif what in SHAPES:
         bench_shapes(what)
     elif what == "fwd1b":
         for T in (1, 3):

@@ -233,6 +233,61 @@ def test_ll_qkv_epilogue_matches_split_path(dev, dtype, T, bias):
     assert float(k2[:, ~free].abs().max()) > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T", [1, 13, 33])
+@pytest.mark.parametrize("bias", [False, True])
+def test_split_qkv_on_fm_with_rms_in_reduce(dev, dtype, T, bias):
+    """Mixed schedule for a qkv linear whose low-latency plan has a ragged last round (70B: 320 blocks): the split-K
+    kernel reads the FM h*w activations and umb_reduce_qkv_rope2 applies 1/rms from the strided sums of squares.
+    Same q / K / V^T as the one-launch low-latency epilogue (to accumulation order), and as the row-major split path
+    on pre-normalised input."""
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import PackedLinear, to_fm
+    gen = torch.Generator(device=dev).manual_seed(T + 100 * bias)
+    Hq, Hkv, D, H, Lmax = 4, 2, 64, 512, 128
+    N = (Hq + 2 * Hkv) * D
+    w = (torch.randn(N, H, device=dev, generator=gen) * 0.05).to(dtype)
+    lin = PackedLinear.from_dense(w, rope=(D, Hq + Hkv))
+    x = torch.randn(T, H, device=dev, generator=gen).to(dtype)
+    b = (torch.randn(N, device=dev, generator=gen) * 0.1).to(dtype) if bias else None
+    pos = torch.randint(0, Lmax, (T,), device=dev, generator=gen, dtype=torch.int32)
+    slot = torch.randperm(Lmax, device=dev, generator=gen)[:T].to(torch.int32)
+    ang = torch.rand(Lmax, D, device=dev, generator=gen) * 6.28
+    cos, sin = torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)
+    G, stride = 70, 80                                         # more groups than one 64-lane pass
+    ssq = torch.rand(T, stride, device=dev, generator=gen) * 4 + 1
+    ssq[:, G:] = 1e9
+    dt = _lib.dtype_code(dtype)
+
+    def caches():
+        return (torch.zeros(T, Hq, D, dtype=dtype, device=dev), torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev),
+                torch.zeros(Hkv, D, Lmax + 32, dtype=dtype, device=dev))
+    q1, k1, v1 = caches()
+    S = max(lin.S, 2)
+    part = torch.empty(S, T, N, dtype=torch.float32, device=dev)
+    f1 = _lib.UmbGemmFused()
+    f1.pad1 = 1
+    _lib.call("umb_gemm_fused", part, to_fm(x), H, lin.w, lin.meta, T, N, H, 0, S, lin.R, 0, f1, dt)
+    _lib.call("umb_reduce_qkv_rope2", part, S, T, Hq, Hkv, D, Lmax, pos, slot, cos, sin, q1, k1, v1, 1, b, ssq, G, stride,
+              float(H), 1e-5, dt)
+    q2, k2, v2 = caches()
+    fx = _fx(pos=pos, slot=slot, cosT=cos, sinT=sin, q_out=q2, k_cache=k2, vt_cache=v2, Hq=Hq, Hkv=Hkv, D=D, Lmax=Lmax,
+             ssq_in=ssq, ssq_groups=G, ssq_in_stride=stride, ssq_dim=float(H), eps=1e-5, **({"bias": b} if bias else {}))
+    lin.apply_ll(x, fx=fx, epi=3)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for a_, b_ in ((q1, q2), (k1, k2), (v1, v2)):
+        scale = float(a_.float().abs().max())
+        assert scale > 0 and float((a_.float() - b_.float()).abs().max()) <= 2 * ulp * scale
+    # fp32 statement of the same thing: (x @ W^T) * inv (+ b), rotated -- on the q rows
+    inv = torch.rsqrt(ssq[:, :G].sum(1) / H + 1e-5)
+    y = (x.float() @ w.float().t()) * inv[:, None] + (b.float() if bias else 0.0)
+    qf = y[:, :Hq * D].view(T, Hq, D)
+    c, s_ = cos[pos.long()].float()[:, None, :], sin[pos.long()].float()[:, None, :]
+    rot = torch.cat([-qf[..., D // 2:], qf[..., :D // 2]], -1)
+    ref = qf * c + rot * s_
+    assert _rel(q1, ref) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+
+
 @pytest.mark.parametrize("N,K,awq", [(3072, 2048, False), (2048, 8192, False), (16384, 2048, False), (128256, 2048, False),
                                      (10240, 8192, True), (8192, 8192, True), (57344, 8192, True), (8192, 28672, True),
                                      (6144, 4096, True), (4096, 14336, True), (28672, 4096, False)])
@@ -309,3 +364,4 @@ def test_shared_kernel_with_fm_buffers(dev, awq, T):
     fx = _fx(ssq_in=ssq, ssq_groups=G, ssq_in_stride=stride, ssq_dim=float(H), eps=1e-5)
     lin.apply_ll(x, fx=fx, epi=2, out=act_ll)
     assert _rel(from_fm(act_ll, T, I), act_rm) < 4e-3
+

@@ -204,11 +204,21 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
                                                              const u16* __restrict__ cosT, const u16* __restrict__ sinT,
                                                              u16* __restrict__ q_out, u16* __restrict__ kc,
                                                              u16* __restrict__ vt, int paired,
-                                                             const u16* __restrict__ bias) {
+                                                             const u16* __restrict__ bias,
+                                                             const float* __restrict__ ssq_in, int ssq_groups,
+                                                             int ssq_stride, float ssq_dim, float eps) {
   const int t = blockIdx.x, head = blockIdx.y;             // head in [0, Hq + 2*Hkv)
   const int N = (Hq + 2 * Hkv) * D;
   const int half = D / 2;
   const int p = pos[t], sl = slot[t];
+  // low-latency schedule: the GEMM ran on h * w (norm weight folded by the producer); the per-token 1/rms from the
+  // producer's sums of squares is applied to the reduced outputs here (it commutes with the matmul)
+  float inv = 1.f;
+  if (ssq_in) {
+    float s = 0.f;
+    for (int q = threadIdx.x; q < ssq_groups; q += 64) s += ssq_in[(long)t * ssq_stride + q];
+    inv = rsqrtf(wave_sum(s) / ssq_dim + eps);
+  }
   const float* base = part + (long)t * N + head * D;
   const long sstride = (long)T * N;
   // paired: the q/k rows were packed as RoPE partner pairs (repack mode 2): columns (2d, 2d+1) <-> (d, d + D/2)
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
       a = base[ca]; b = base[cb];
       for (int s = 1; s < S; ++s) { a += base[s * sstride + ca]; b += base[s * sstride + cb]; }
     }
+    a *= inv; b *= inv;
     if (bias) {        // F.linear(x, W, b) (qwen.py:94-96): bias joins the fp32 accumulator, one rounding; HF feature order
       a += P::to_f(bias[head * D + d]); b += P::to_f(bias[head * D + d + half]);
     }
@@ -339,18 +350,26 @@ extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, voi
   return UMB_OK;
 }
 
+extern "C" int umb_reduce_qkv_rope2(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax,
+                                    const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
+                                    void* k_cache, void* vt_cache, int paired, const void* bias, const float* ssq_in,
+                                    int ssq_groups, int ssq_stride, float ssq_dim, float eps, int dtype, hipStream_t st) {
+  if (D % 2 || (ssq_in && (ssq_groups < 1 || ssq_stride < ssq_groups || ssq_dim <= 0.f))) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
+                       Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
+                       (u16*)vt_cache, paired, (const u16*)bias, ssq_in, ssq_groups, ssq_stride, ssq_dim, eps);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
 extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, int Hkv, int D, int Lmax,
                                    const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
                                    void* k_cache, void* vt_cache, int paired, const void* bias, int dtype,
                                    hipStream_t st) {
-  if (D % 2) return UMB_EINVAL;
-  DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
-                       Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
-                       (u16*)vt_cache, paired, (const u16*)bias);
-  })
-  UMB_LAUNCH_CHECK();
-  return UMB_OK;
+  return umb_reduce_qkv_rope2(partial, S, T, Hq, Hkv, D, Lmax, pos, slot, cosT, sinT, q_out, k_cache, vt_cache, paired,
+                              bias, nullptr, 0, 0, 0.f, 0.f, dtype, st);
 }
 
 extern "C" int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,

@@ -25,7 +25,7 @@
 #include <type_traits>
 #include <cstdlib>
 #ifndef UMB_CB1
-#define UMB_CB1 4
+#define UMB_CB1 2        // k-blocks per LDS chunk at <= 16 tokens: 2 -> 4-stage weight ring, ~2x fewer registers, 3-4 waves per SIMD
 #endif
 
 // ------------------------------------------------------------------ repack (load time)
@@ -282,11 +282,15 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
   for (int tt = 0; tt < TT; ++tt) {
     u32x4 b[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = xf[(tt * 4 + s) * 64 + lane];
+    for (int s = 0; s < 4; ++s) {
+      b[s] = xf[(tt * 4 + s) * 64 + lane];
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[r][tt] = P::mfma(wf[r][s], b[s], acc[r][tt]);
+      for (int r = 0; r < R; ++r) {
+        acc[r][tt] = P::mfma(wf[r][s], b[s], acc[r][tt]);
+      }
   }
 }
 
@@ -339,65 +343,122 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[r][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const WaveBase<AWQ, R> wb = wave_base<AWQ, R>(wp, meta, active ? nt0 : 0, KB);
   const int nkb = kb1 - kb0;
   constexpr int PF = 2 * CB;                 // ring of PF weight stages: PF x R KiB-tiles in flight per wave
-  // FULL: the slab is a whole number of rings and every wave owns tiles -> no per-k-block predicates at all
-  const bool full = (nkb % PF == 0) && (NT % (4 * R) == 0) && nkb > 0;
-
-  u32x4 xr[FPW];
-  Stage<P, AWQ, R> st[PF];
-  auto run = [&](auto full_c) {
-    constexpr bool FULL = decltype(full_c)::value;
-    auto load_x = [&](int c) {
-      const u16* xb = x + (long)(kb0 + c * CB) * 128;                  // uniform
+  // ---- streams.  Every load of the main loop is an unconditional buffer load: a k-block past the end of the slab, a
+  // token row past T or the whole stream of a wave without tiles is OUT OF RANGE of its descriptor -> zeros, no fetch.
+  // No load sits behind a branch or an exec mask, so the compiler's vmcnt bookkeeping stays exact and the ring really
+  // stays PF stages deep (with predicated loads it drained the counter to zero at every chunk: the weight stream ran
+  // one chunk deep, 4.1 TB/s where the same access pattern without compute streams 6.4 TB/s).
+  __amdgpu_buffer_rsrc_t rw[R], rm[R];
 #pragma unroll
-      for (int i = 0; i < FPW; ++i) {
-        const int f = i * 4 + wv;
-        const int kl = f / (TT * 4);
-        const int tok = ((f >> 2) % TT) * 16 + j;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        const bool ok = tok < T && (FULL || kb0 + c * CB + kl < kb1);
-        if (fx.x_fm)    // fragment order: the B fragment of (k32-step, token tile) is one contiguous 1 KiB
-          xr[i] = (FULL || kb0 + c * CB + kl < kb1)
-                      ? reinterpret_cast<const u32x4*>(x)[((long)((kb0 + c * CB + kl) * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 64 + lane] : z;
-        else
-          xr[i] = ok ? *reinterpret_cast<const u32x4*>(xb + (long)tok * ldx + kl * 128 + (f & 3) * 32 + g * 8) : z;
-      }
-    };
-    auto store_x = [&](int c) {
-#pragma unroll
-      for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xr[i];
-    };
-    load_x(0);
-    if (FULL || active) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i)
-        if (FULL || kb0 + i < kb1) stage_load<P, AWQ, R>(st[i], wb, kb0 + i, lane);
+  for (int r = 0; r < R; ++r) {
+    const int nt = active ? nt0 + r : 0;
+    const bool live = active && nkb > 0;
+    if (AWQ) {
+      const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);        // tile order [N/64][K/128][4]
+      rw[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp + tile0 * 64), 0,
+                                                live ? (unsigned)(kb1 - 1) * 4096u + 1024u : 0u, 0x00020000);
+      rm[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(meta + tile0 * 64), 0,
+                                                live ? (unsigned)(kb1 - 1) * 256u + 64u : 0u, 0x00020000);
+    } else {
+      rw[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp + ((long)nt * KB) * 256), 0,
+                                                live ? (unsigned)kb1 * 4096u : 0u, 0x00020000);
+      rm[r] = rw[r];
     }
-    auto chunk = [&](int c, auto half) {
-      constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
-      store_x(c);
-      __syncthreads();
-      if (c + 1 < nchunks) load_x(c + 1);
-      if (FULL || active) {
-        const u32x4* xc = xs + (c & 1) * F * 64;
-        const bool more = (c + 2) * CB < nkb;             // FULL: one uniform refill decision per chunk
+  }
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u16*>(x), 0, fx.x_fm ? (unsigned)(TT * 16 * 2) * (unsigned)K : (unsigned)(((long)(T - 1) * ldx + K) * 2),
+      0x00020000);
+  int voffx[FPW];
 #pragma unroll
-        for (int kl = 0; kl < CB; ++kl) {
-          const int kb = kb0 + c * CB + kl;
-          if (FULL || kb < kb1) {
-            stage_compute<P, AWQ, TT, R>(st[H * CB + kl], xc + kl * TT * 4 * 64, lane, acc);
-            if (FULL ? more : (kb + PF < kb1)) stage_load<P, AWQ, R>(st[H * CB + kl], wb, kb + PF, lane);
-          }
-        }
+  for (int i = 0; i < FPW; ++i) {
+    const int tok = (((i * 4) >> 2) % TT) * 16 + j;                     // (f >> 2) % TT with f = i*4 + wv: wv < 4 drops out
+    voffx[i] = fx.x_fm ? lane * 16 : (tok < T ? (int)(((long)tok * ldx + g * 8) * 2) : (int)0x80000000);
+  }
+  // int4 metadata ({scale, zero} per row per k-block, 64 B per tile): ONE half-wave load per chunk brings the wave's
+  // R tiles x CB k-blocks (16 B per lane), staged through a wave-private LDS slot and read back per k-block --
+  // instead of R x CB separate 64-byte loads (they cost 3.5 us of a 55 us gate/up launch: 6 % of the bytes).
+  constexpr int XD = (TT == 1) ? 2 : 1;              // x register ring: chunks ahead (TT > 1: registers)
+  constexpr int MSLOT = 1024;                        // staged metadata per wave per ring half (64 lanes x 16 B)
+  unsigned char* ms = smem + (size_t)2 * F * 1024 + wv * 2 * MSLOT;
+  __amdgpu_buffer_rsrc_t rmeta = rm[0];
+  int voff_m = (int)0x80000000;
+  if (AWQ) {
+    const int nt = active ? nt0 : 0;
+    const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);
+    rmeta = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(meta + tile0 * 64), 0,
+                                              (active && nkb > 0) ? (unsigned)(kb1 - 1) * 256u + R * 64u : 0u, 0x00020000);
+    if (lane < R * CB * 4) voff_m = (lane / (R * 4)) * 256 + (lane % (R * 4)) * 16;
+  }
+  u32x4 xr[XD][FPW];
+  u32x4 mr[2];
+  Stage<P, AWQ, R> st[PF];
+  auto sload = [&](Stage<P, AWQ, R>& sg, int kb) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (AWQ) {
+        // the k offset rides in the VGPR offset: that is the part of the address the range check certainly covers
+        sg.a[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rw[r], lane * 16 + kb * 4096, 0, 2);   // non-temporal
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          sg.a[r][AWQ ? 0 : s2] = __builtin_amdgcn_raw_buffer_load_b128(rw[r], lane * 16 + kb * 4096 + s2 * 1024, 0, 2);
       }
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-      chunk(c, std::integral_constant<int, 0>{});
-      if (FULL || c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{});
     }
   };
+  auto load_m = [&](int c) { return __builtin_amdgcn_raw_buffer_load_b128(rmeta, voff_m + (kb0 + c * CB) * 256, 0, 0); };
+  auto load_x = [&](u32x4 (&xq)[FPW], int c) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+      const int f = i * 4 + wv;
+      const int kb = kb0 + c * CB + f / (TT * 4);
+      // FM: the B fragment of (k32-step, token tile) is one contiguous 1 KiB; row-major: 16 bytes of row tok at k
+      const int soff = fx.x_fm ? ((kb * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 1024 : (kb * 128 + (f & 3) * 32) * 2;
+      xq[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[i] + soff, 0, 0);
+    }
+  };
+  auto store_x = [&](const u32x4 (&xq)[FPW], int c) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xq[i];
+  };
+  const int nfull = nkb > 0 ? nkb / CB : 0;  // chunks whose k-blocks all lie inside the slab
+  auto chunk = [&](int c, auto half, auto guard) {
+    constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
+    constexpr bool G = decltype(guard)::value;         // ragged tail: skip the k-blocks past the slab (compute only)
+    constexpr int XH = XD == 2 ? H : 0;
+    store_x(xr[XH], c);
+    if (AWQ) *reinterpret_cast<u32x4*>(ms + H * MSLOT + lane * 16) = mr[H];
+    __syncthreads();
+    // everything loaded from here on is for chunk c + 2 (x of TT > 1: c + 1), in the order it will be consumed
+    load_x(xr[XH], c + XD);
+    if (AWQ) mr[H] = load_m(c + 2);
+    const u32x4* xc = xs + (c & 1) * F * 64;
+#pragma unroll
+    for (int kl = 0; kl < CB; ++kl) {
+      const int kb = kb0 + c * CB + kl;
+      Stage<P, AWQ, R>& sg = st[H * CB + kl];
+      if (!G || kb < kb1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const unsigned char* mrec = ms + H * MSLOT + (kl * R + r) * 64;
+          if (AWQ == 1) sg.m4[r] = *reinterpret_cast<const u32x4*>(mrec + g * 16);
+          if (AWQ == 2) sg.m1[r] = *reinterpret_cast<const unsigned*>(mrec + j * 4);
+        }
+        stage_compute<P, AWQ, TT, R>(sg, xc + kl * TT * 4 * 64, lane, acc);
+      }
+      sload(sg, kb + PF);
+    }
+  };
+  // prologue, in consumption order: chunk 0 (x, metadata, weights), then chunk 1
+  load_x(xr[0], 0);
+  if (AWQ) mr[0] = load_m(0);
+#pragma unroll
+  for (int i = 0; i < CB; ++i) sload(st[i], kb0 + i);
+  if (XD == 2) load_x(xr[XD - 1], 1);
+  if (AWQ) mr[1] = load_m(1);
+#pragma unroll
+  for (int i = CB; i < PF; ++i) sload(st[i], kb0 + i);
   // per-token 1/rms of the producer's residual stream (its loads overlap the weight stream)
   float inv[TT];
 #pragma unroll
@@ -414,8 +475,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
       inv[tt] = rsqrtf(a / fx.ssq_dim + fx.eps);
     }
   }
-  if (full) run(std::true_type{});
-  else run(std::false_type{});
+  {
+    int c = 0;
+    for (; c + 2 <= nfull; c += 2) {                   // steady state: no branch, no predicate
+      chunk(c, std::integral_constant<int, 0>{}, std::false_type{});
+      chunk(c + 1, std::integral_constant<int, 1>{}, std::false_type{});
+    }
+    for (; c < nchunks; c += 2) {                      // ragged tail of the slab
+      chunk(c, std::integral_constant<int, 0>{}, std::true_type{});
+      if (c + 1 < nchunks) chunk(c + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+  }
 
   // ------------------------------------------------------------------ direct epilogues (no cross-block step)
   if (epi <= EPI_SILU) {
@@ -957,7 +1027,7 @@ static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, flo
                     int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
   const int NT = N / 16;
   const int nblk = (NT + 4 * R - 1) / (4 * R);
-  size_t smem = (size_t)2 * CB * TT * 4 * 1024;
+  size_t smem = (size_t)2 * CB * TT * 4 * 1024 + (AWQ ? 4 * 2 * 1024 : 0);   // x chunks (double buffered) + staged int4 metadata
   if (smem > 64 * 1024) {
     static bool once = false;      // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!once) {
@@ -1019,7 +1089,9 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     if (fx.slot) fx.slot += t0;
     if (fx.q_out) fx.q_out += (long)t0 * fx.Hq * fx.D;
     int rc;
-    if (tn <= 16) rc = launch_r<P, AWQ, 1, UMB_CB1>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    static const int cb1 = getenv("UMB_CB") ? atoi(getenv("UMB_CB")) : UMB_CB1;
+    if (tn <= 16 && cb1 == 2) rc = launch_r<P, AWQ, 1, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    else if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
     if (rc) return rc;

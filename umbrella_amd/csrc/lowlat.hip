@@ -564,6 +564,32 @@ extern "C" int umb_from_fm(void* out, const void* x_fm, int T, int K, int dtype,
   return UMB_OK;
 }
 
+// ---- measurement probe: the read-only streaming rate this device delivers (what every weight-streaming kernel here is
+// priced against besides the 8 TB/s spec sheet: boxes of the same part differed by 20 % on it).  16-byte non-temporal
+// loads, 8 in flight per lane, block-contiguous 32 KiB spans; the xor sink defeats dead-code elimination.
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const long stride = (long)gridDim.x * 2048;
+  for (long base = (long)blockIdx.x * 2048 + threadIdx.x; base < n16; base += stride) {
+    u32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long q = base + i * 256;
+      v[i] = q < n16 ? __builtin_nontemporal_load(p + q) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc ^= v[i];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) *sink = 1u;
+}
+
+extern "C" int umb_stream_read(const void* p, size_t bytes, void* sink, hipStream_t st) {
+  if (bytes % 16 || !sink) return UMB_EINVAL;
+  hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, st, (const u32x4*)p, (long)(bytes / 16), (unsigned*)sink);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
 // ---- embedding gather + per-forward index prep for the low-latency schedule (F.embedding, llama.py:124):
 // h (row-major), hw = h * norm_w (FM), ssq[t][0..4) = per-wave sums of h^2; positions / slots / prefix resolved as in
 // embed_prep_kernel (epilogue.hip) and clamped into the caches.

@@ -139,6 +139,18 @@ static inline bool gu_on_shared_kernel(const UmbLinear& l) {
   return l.S == 1 && l.N / (64 * (l.R > 0 ? l.R : 1)) >= 256;
 }
 
+// qkv on the split-K kernel + reduce: when the low-latency plan leaves a ragged last round (blocks not a multiple of the
+// CU count and fewer than two rounds).  UMB_LL_QKV = ll | split overrides (experiments).  Shape-only.
+static inline bool qkv_on_split_kernel(const UmbLinear& l) {
+  static const char* env = getenv("UMB_LL_QKV");
+  if (env && env[0] == 'l') return false;
+  if (env && env[0] == 's') return l.S > 1;
+  int R, WN, WK, NW;
+  umb_ll_plan(l.N, l.K, l.awq, &R, &WN, &WK, &NW);
+  const int blocks = (l.N / 16 / R + WN - 1) / WN;
+  return l.S > 1 && blocks > 256 && blocks < 512;
+}
+
 static int prologue_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
   if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
   return umb_embed_ll(ws->h, s->skip_embed ? nullptr : m->embed, m->H, m->V, m->Lmax, s->T, s->tokens, s->positions,
@@ -156,12 +168,23 @@ static int layer_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
   const int og = ll_groups(ly.o), dg = ll_groups(ly.down);
   if (og > ws->ssq_stride || dg > ws->ssq_stride) return UMB_EINVAL;
-  // 1. qkv: 1/rms, (+bias), RoPE at the tree positions, q out, K / V appended at their slots
+  // 1. qkv: 1/rms, (+bias), RoPE at the tree positions, q out, K / V appended at their slots.  A linear whose row groups
+  // do not tile the 256 CUs in whole rounds (70B: 320 blocks) runs split-K on the LDS-shared kernel + its reduce kernel
+  // instead (16.9 + 5.0 vs 24.5 us), reading the same FM activations.
+  if (qkv_on_split_kernel(ly.qkv)) {
+    UmbGemmFused fs = {};
+    fs.pad1 = 1;                                            // x in FM layout
+    CK(lin(ly.qkv, ws->hw, m->H, ws->partial, T, dt, st, 0, &fs));
+    CK(umb_reduce_qkv_rope2(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
+                            m->rope_sin, ws->q, kc, vt, /*paired=*/1, ly.qkv_bias, ws->ssq, *ssq_groups, ws->ssq_stride,
+                            (float)m->H, m->eps, dt, st));
+  } else {
   UmbGemmLL fq = {};
   fq.ssq_in = ws->ssq; fq.ssq_groups = *ssq_groups; fq.ssq_in_stride = ws->ssq_stride; fq.ssq_dim = (float)m->H; fq.eps = m->eps;
   fq.pos = ws->pos; fq.slot = ws->slot; fq.cosT = m->rope_cos; fq.sinT = m->rope_sin; fq.q_out = ws->q; fq.k_cache = kc;
   fq.vt_cache = vt; fq.bias = ly.qkv_bias; fq.Hq = m->Hq; fq.Hkv = m->Hkv; fq.D = m->D; fq.Lmax = m->Lmax;
   CK(umb_gemm_ll(nullptr, ws->hw, ly.qkv.w, ly.qkv.meta, T, ly.qkv.N, ly.qkv.K, ly.qkv.awq, 3, &fq, dt, st));
+  }
   // 2. tree attention, output in FM layout for the o-projection
   CK(umb_tree_attn2(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
                     s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,

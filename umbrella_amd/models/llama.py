@@ -184,7 +184,10 @@ class Llama(LLMBase):
         self.fused = os.environ.get("UMB_FUSED", "0") == "1"
         # sched "ll": low-latency schedule for forwards of <= 64 rows -- 5 launches / layer, whole-K workgroups with the
         # layer's elementwise work as GEMM epilogues, activations in MFMA fragment order (csrc/lowlat.hip)
-        self.sched = os.environ.get("UMB_SCHED", "ll")
+        # "split": 8 launches / layer, split-K GEMMs on the LDS-shared kernel + reduce kernels.  Default "auto": int4 (AWQ)
+        # checkpoints take "split" (70B tree verify 2.30 vs 2.58 ms per 16 layers since the shared kernel's weight ring
+        # stopped draining), dense 16-bit models "ll" (1B draft forward 0.77 vs 0.84 ms)
+        self.sched = os.environ.get("UMB_SCHED", "auto")
         if config is None and not os.path.isdir(model_name) and state_dict is None:
             local = _resolve_hub_snapshot(model_name)             # HF cache, offline
             if local is not None:
@@ -198,6 +201,8 @@ class Llama(LLMBase):
         else:
             raise ValueError(f"Model type '{model_name}' is not supported. Supported types: {list(KNOWN.keys())} "
                              "or a local directory with config.json")
+        if self.sched == "auto":
+            self.sched = "split" if self.config.awq else "ll"
         c = self.config
         if c.attention_bias:
             self.fused = False                    # projection bias: default / low-latency schedules only
