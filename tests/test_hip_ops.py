@@ -669,7 +669,11 @@ def test_verify_gemm_wide_full_width(dev, awq, T):
     rows = sorted(set(r for r in rows if 0 <= r < T))
     y1 = torch.cat([lin.apply(x[r:r + 1].contiguous()) for r in rows])
     scale = float(y1.abs().max())
-    assert float((y[rows] - y1).abs().max()) <= 2e-5 * scale + 1e-6, float((y[rows] - y1).abs().max())
+    # dense: fp32 summation order only.  int4: the wide kernels dequantise exactly (W = fp16((q - z) s)) while launches of
+    # <= 64 rows use the folded form s (sum q x - z sum x) -- the difference is the fp16 rounding of the weights, 2^-11
+    # relative per weight, < 2e-3 of the row scale after the sum (same bound as against the oracle below)
+    tol = 2e-3 if awq else 2e-5
+    assert float((y[rows] - y1).abs().max()) <= tol * scale + 1e-6, float((y[rows] - y1).abs().max())
     if awq:
         from test_hip_engine import _awq_dequant_torch
         wd = _awq_dequant_torch(qw[:, :16], qz[:, :16], sc[:, :128]).float()       # first 128 output columns

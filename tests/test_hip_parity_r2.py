@@ -341,7 +341,8 @@ def test_gemm_awq_8b_full_size_properties(dev, N, K):
         yw = lin.apply(xw)
         rows = [0, 63, 64, 128, T - 1]
         y1 = torch.cat([lin.apply(xw[r:r + 1].contiguous()) for r in rows])
-        assert float((yw[rows] - y1).abs().max()) <= 2e-5 * float(y1.abs().max()) + 1e-6
+        # wide kernels: exact fp16 dequant; <= 64-row launches: folded form -> the fp16 rounding of the weights apart
+        assert float((yw[rows] - y1).abs().max()) <= 2e-3 * float(y1.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("N,K", SHAPES_8B + [(128256, 4096)])

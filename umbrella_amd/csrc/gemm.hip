@@ -179,65 +179,69 @@ template <typename P, int AWQ, int TT, int R>
 __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const u32x4* xf, int lane,
                                               f32x4 (&acc)[R][TT]) {
   if (AWQ == 1) {
-    // folded dequant (any activation dtype): the MFMA runs on the raw codes with a magic exponent and per 128-k group
-    //   out += s * ( sum_k (c_k + q_k) x_k - sum_k c_k x_k - z * sum_k x_k ),
-    // the two x-only sums from MFMAs against constant fragments (shared by the R tiles).  fp16: nibbles at mantissa
-    // bits 0..3 take the magic 1024, nibbles at bits 4..7 the magic 64 -> 5 VALU per 8 weights (1 shift + 4 v_and_or)
-    // instead of 13 for the exact in-register dequant of AWQ == 2; bf16 (7 mantissa bits): magic 128, 3 shifts.
+    // folded dequant (any activation dtype): the MFMA runs on the raw codes under ONE magic exponent,
+    //   out += s * ( sum_k (C + q_k) x_k - (C + z) * sum_k x_k )        per 128-k group,
+    // sum_k x_k from one MFMA chain against a constant fragment of ones (shared by the R tiles).  fp16: every nibble is
+    // moved to mantissa bits 4..7 under 0x5400 (C = 64: 3 shifts + 4 v_and_or per 8 weights); bf16 (7 mantissa bits):
+    // bits 0..3 under 0x4300 (C = 128).  On gfx950 the packed-fp16 and three-operand integer VALU ops issue at HALF the
+    // rate of plain VOP2 ops (scripts/probe/valu_probe.hip: 1.9 vs 1.0 ns per wave instruction), so the exact
+    // in-register dequant of AWQ == 2 costs 95 ns of VALU per KiB tile against 160 ns of HBM time -- too much to hide;
+    // this form costs ~60 ns (unpack 4 x 10.6 + the fp32 step 8 mixed-precision FMAs).
     constexpr bool HALF = std::is_same<P, F16>::value;
+    constexpr float COFF = HALF ? 64.f : 128.f;
     u32x4 b[TT][4];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) b[tt][s] = xf[(tt * 4 + s) * 64 + lane];
-    const unsigned nlo = HALF ? 0xE400E400u : 0xC300C300u;           // -1024 | -128
-    const unsigned nhi = HALF ? 0xD400D400u : 0xC300C300u;           // -64   | -128
-    const u32x4 negc = {nlo, nhi, nlo, nhi};
     const u32x4 ones = {P::ONE2, P::ONE2, P::ONE2, P::ONE2};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    unsigned magic_lo = P::MAGIC, magic_hi = 0x54005400u;
-    asm volatile("" : "+v"(magic_lo));                               // pinned in VGPRs: (w & mask) | magic selects v_and_or_b32
-    asm volatile("" : "+v"(magic_hi));
-    f32x4 xs[TT], np[TT];
+    unsigned magic = HALF ? 0x54005400u : P::MAGIC;
+    asm volatile("" : "+v"(magic));                                  // pinned in a VGPR: (w & mask) | magic selects v_and_or_b32
+    f32x4 xs[TT], xc[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
-      xs[tt] = zero; np[tt] = zero;
+      xs[tt] = zero;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
-        np[tt] = P::mfma(negc, b[tt][s], np[tt]);
-      }
+      for (int s = 0; s < 4; ++s) xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
+      xc[tt] = xs[tt] * (-COFF);                                      // C-in of the code chains: - C sum_k x_k
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       f32x4 ga[TT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) ga[tt] = np[tt];                // C-in: - sum_k c_k x_k
+      for (int tt = 0; tt < TT; ++tt) ga[tt] = xc[tt];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const unsigned w = st.a[r][0][s];
         u32x4 f;
         if constexpr (HALF) {
-          const unsigned w8 = w >> 8;
-          f[0] = (w & 0x000F000Fu) | magic_lo;
-          f[1] = (w & 0x00F000F0u) | magic_hi;
-          f[2] = (w8 & 0x000F000Fu) | magic_lo;
-          f[3] = (w8 & 0x00F000F0u) | magic_hi;
+          f[0] = ((w << 4) & 0x00F000F0u) | magic;
+          f[1] = (w & 0x00F000F0u) | magic;
+          f[2] = ((w >> 4) & 0x00F000F0u) | magic;
+          f[3] = ((w >> 8) & 0x00F000F0u) | magic;
         } else {
-          f[0] = (w & 0x000F000Fu) | magic_lo;
-          f[1] = ((w >> 4) & 0x000F000Fu) | magic_lo;
-          f[2] = ((w >> 8) & 0x000F000Fu) | magic_lo;
-          f[3] = ((w >> 12) & 0x000F000Fu) | magic_lo;
+          f[0] = (w & 0x000F000Fu) | magic;
+          f[1] = ((w >> 4) & 0x000F000Fu) | magic;
+          f[2] = ((w >> 8) & 0x000F000Fu) | magic;
+          f[3] = ((w >> 12) & 0x000F000Fu) | magic;
         }
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) ga[tt] = P::mfma(f, b[tt][s], ga[tt]);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float sc = F16::to_f((u16)(st.m4[r][e] & 0xffffu));
-        const float nz = -F16::to_f((u16)(st.m4[r][e] >> 16));
+        // ga = sum_k q_k x_k.  {scale, zero} are fp16 in the metadata whatever the activation dtype: two mixed-precision
+        // FMAs per output (v_fma_mix_f32 reads the halves in place); the empty asm keeps the SLP vectoriser from pairing
+        // them into v_pk_fma_f32 behind eight conversions
+        const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(st.m4[r][e] & 0xffffu));
+        const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(st.m4[r][e] >> 16));
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[r][tt][e] = fmaf(sc, fmaf(nz, xs[tt][e], ga[tt][e]), acc[r][tt][e]);
+        for (int tt = 0; tt < TT; ++tt) {
+          float t = __builtin_fmaf(-(float)zf, xs[tt][e], ga[tt][e]);
+          asm("" : "+v"(t));
+          acc[r][tt][e] = __builtin_fmaf((float)sc, t, acc[r][tt][e]);
+        }
       }
     }
     return;
@@ -1132,13 +1136,14 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   }
   if (fx.ssq_in && (fx.ssq_groups % 4 || fx.ssq_stride % 4)) return UMB_EINVAL;
   if ((fx.x_fm || fx.out_fm) && T > 64) return UMB_EINVAL;      // FM buffers hold one launch of <= 64 tokens
-  // fp16 int4: exact in-register dequant (bit-identical weights to awq_ext.dequantize_weights_cuda).  The folded form
-  // s * sum (q - z) x (5 instead of 13 VALU per 8 weights, UMB_AWQ_FOLDED=1, T <= 64) was measured SLOWER in this
-  // kernel: its per-row metadata quad and the two constant-fragment MFMA chains cost 256 registers (2 waves per SIMD
-  // instead of 3.5) -- 70B gate/up 83-85 vs 66-67 us on the same box; it is what the low-latency family uses, where the
-  // register budget is spent on operand rings anyway.
-  static const bool awq_folded = getenv("UMB_AWQ_FOLDED") != nullptr;
-  if (awq && dtype == UMB_F16 && !(awq_folded && T <= 64))
+  // fp16 int4, T <= 64 (HBM-bound launches): the FOLDED form s * (sum q x - z sum x) in fp32 -- 63 ns of VALU per KiB
+  // tile instead of 101 for the exact in-register dequant (gfx950 issues packed-fp16 and 3-operand integer VALU ops at half
+  // rate, scripts/probe/valu_probe.hip), 70B gate/up 47.9 vs 52.6 us on the same box.  It computes the real-valued
+  // (q - z) * s model without rounding each weight to fp16 first: within 2^-11 relative per weight of the reference's
+  // awq_ext-dequantised weights (tests: 2e-3 of the row scale), and what the low-latency family always did.
+  // T > 64 (matrix-pipe bound verify GEMMs) and UMB_AWQ_EXACT=1: exact dequant, W = fp16((q - z) * s) bit for bit.
+  static const bool awq_exact = getenv("UMB_AWQ_EXACT") != nullptr;
+  if (awq && dtype == UMB_F16 && (awq_exact || T > 64))
     return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
   DISPATCH_DTYPE(dtype, {
     if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
