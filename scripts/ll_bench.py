@@ -151,6 +151,8 @@ def bench_stream():
         k = min(buf.numel() // n, 8)
         us = timeit(lambda i: _lib.call("umb_stream_read", buf[(i % k) * n:], n, sink), reps=40, warm=4)
         print(f"stream read {mb} MB launches (rotating {k} regions): {us:.1f} us -> {n/us/1e3:.0f} GB/s", flush=True)
+        us = timeit(lambda i: _lib.call("umb_stream_read", buf, n, sink), reps=40, warm=4)
+        print(f"stream read {mb} MB launches (SAME region, Infinity Cache resident if it fits): {us:.1f} us -> {n/us/1e3:.0f} GB/s", flush=True)
 
 
 for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:

@@ -126,3 +126,49 @@ def test_budget_tree_generator_and_shipped_mi355x_tree():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "umbrella_amd", "trees", "mi355x_70b_awq_1b-T16d3.json")) as f:
         assert json.load(f) == generate_budget_tree(16, 3, DEFAULT_ACC)
+
+
+def test_spec_bench_aggregation():
+    """examples/spec_bench.py keeps the reference's loop order and sums (reference examples/spec_bench.py:96-134):
+    prefill -> decode -> append -> decode -> reset per prompt; Avg Accept Tokens = sum(tokens) / sum(target steps) and
+    TPOT = 1000 * sum(seconds) / sum(tokens), per category and overall -- NOT means of per-prompt ratios."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "spec_bench_example", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "spec_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class FakeEngine:
+        def __init__(self, results):
+            self.results, self.calls = list(results), []
+
+        def _prefill(self, ids):
+            self.calls.append(("prefill", int(ids.numel())))
+            return True
+
+        def _append(self, ids):
+            self.calls.append(("append", int(ids.numel())))
+            return int(ids.numel()) != 999                      # a turn that does not fit ends the prompt
+
+        def speculative_decoding(self, max_new_tokens):
+            self.calls.append(("decode", max_new_tokens))
+            return self.results.pop(0)
+
+        def reset(self):
+            self.calls.append(("reset",))
+
+    import torch
+    t = lambda n: torch.zeros(1, n, dtype=torch.long)
+    res = [(100, 0.5, 30), (40, 0.25, 16), (64, 0.4, 16), (7, 0.1, 7)]
+    eng = FakeEngine(res)
+    prompts = [("writing", [t(64), t(32)]), ("math", [t(128), t(999)]), ("writing", [t(256)])]
+    per, total = mod.run_prompts(eng, prompts, gen_len=77)
+    assert eng.calls == [("prefill", 64), ("decode", 77), ("append", 32), ("decode", 77), ("reset",),
+                         ("prefill", 128), ("decode", 77), ("append", 999), ("reset",),
+                         ("prefill", 256), ("decode", 77), ("reset",)]
+    assert per["writing"] == [147, 0.85, 53] and per["math"] == [64, 0.4, 16] and total == [211, 1.25, 69]
+    rows = mod.report(per, total)
+    assert rows[0] == "math | Avg Accept Tokens 4.00 | TPOT 6.25 ms"
+    assert rows[1] == "writing | Avg Accept Tokens {:.2f} | TPOT {:.2f} ms".format(147 / 53, 1000 * 0.85 / 147)
+    assert rows[2].startswith("Summary | Avg Accept Tokens {:.2f} | TPOT {:.2f} ms".format(211 / 69, 1000 * 1.25 / 211))
