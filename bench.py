@@ -376,15 +376,14 @@ def main():
             import hashlib
             with open(os.path.join(ROOT, "umbrella_amd", "csrc", "gemm.hip"), "rb") as f:
                 src_hash = hashlib.sha256(f.read()).hexdigest()[:16]
-            for pmc_name in ("r02_pmc_gemm70b_traffic.json", "r01_pmc_gemm70b_traffic.json"):
+            for pmc_name in ("r02_pmc_gemm70b_traffic.json",):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
                     with open(pmc) as f:
                         rec = json.load(f)
-                    if rec.get("gemm_hip_sha256_16") in (None, src_hash):
+                    if rec.get("gemm_hip_sha256_16") == src_hash:      # a figure taken on other kernel source is not reported
                         traffic = rec["gate_up_traffic_bytes"]
-                        tsrc = f"static: profiles/{pmc_name} (separate rocprofv3 --pmc passes" + \
-                               (", same gemm.hip)" if rec.get("gemm_hip_sha256_16") else ", kernel source hash not recorded)")
+                        tsrc = f"static: profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this gemm.hip)"
                         break
             out["roofline"] = {"bound": "hbm", "kernel": f"{dom['family']} {'int4' if m.config.awq else 'dense'} gate_up "
                                                        f"N={dom['N']} K={dom['K']} T={eng.tree_size}",

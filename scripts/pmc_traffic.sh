@@ -25,7 +25,7 @@ g = str(448 * 256)
 traffic = raw["FETCH_SIZE"][g]["mean_KB"] * 1024 * 2 + raw["WRITE_SIZE"][g]["mean_KB"] * 1024
 src = open(os.path.join(root, "umbrella_amd", "csrc", "gemm.hip"), "rb").read()
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python scripts/gemm_bench.py 70b (scripts/pmc_traffic.sh)",
-       "kernel": "skinny_gemm_kernel<F16, AWQ=2, TT=1, R=2, CB=4> gate_up N=57344 K=8192 T=13 (grid 448 x 256)",
+       "kernel": "skinny_gemm_kernel<F16, int4 (folded dequant), TT=1, R=2> gate_up N=57344 K=8192 T=13 (grid 448 x 256)",
        "correction": "FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports half the bytes of wide coalesced streaming reads); WRITE_SIZE [KB] x 1024",
        "raw": raw, "gate_up_traffic_bytes": traffic, "gate_up_algorithmic_bytes": 249561088,
        "gemm_hip_sha256_16": hashlib.sha256(src).hexdigest()[:16]}
