@@ -20,6 +20,8 @@ gen = torch.Generator(device=dev).manual_seed(0)
 SHAPES = {"70b": (torch.float16, 13, [("qkv", 10240, 8192, 1, 0), ("o", 8192, 8192, 1, 0), ("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 1, 0)]),
           "1b": (torch.float16, 3, [("qkv", 3072, 2048, 0, 0), ("o", 2048, 2048, 0, 0), ("gu", 16384, 2048, 0, 1), ("down", 2048, 8192, 0, 0),
                                     ("head", 128256, 2048, 0, 0)]),
+          # balance experiment: 4096 n-tiles = 512 blocks = exactly 2 per CU (the real gate/up has 3584 = 448 blocks)
+          "bal": (torch.float16, 13, [("gu", 57344, 8192, 1, 1), ("gu", 65536, 8192, 1, 1), ("gu", 49152, 8192, 1, 1)]),
           "8b": (torch.bfloat16, 31, [("qkv", 6144, 4096, 0, 0), ("o", 4096, 4096, 0, 0), ("gu", 28672, 4096, 0, 1), ("down", 4096, 14336, 0, 0)])}
 
 

@@ -185,8 +185,9 @@ class Llama(LLMBase):
         # sched "ll": low-latency schedule for forwards of <= 64 rows -- 5 launches / layer, whole-K workgroups with the
         # layer's elementwise work as GEMM epilogues, activations in MFMA fragment order (csrc/lowlat.hip)
         # "split": 8 launches / layer, split-K GEMMs on the LDS-shared kernel + reduce kernels.  Default "auto": int4 (AWQ)
-        # checkpoints take "split" (70B tree verify 2.30 vs 2.58 ms per 16 layers since the shared kernel's weight ring
-        # stopped draining), dense 16-bit models "ll" (1B draft forward 0.77 vs 0.84 ms)
+        # checkpoints and models of hidden size >= 4096 take "split" (70B-AWQ tree verify 2.30 vs 2.58 ms per 16 layers,
+        # 8B bf16 T = 31 forward 4.51 vs 5.09 ms, since the shared kernel's weight ring stopped draining -- DESIGN.md);
+        # small dense models, where launches dominate, "ll" (1B draft forward 0.77 vs 0.84 ms)
         self.sched = os.environ.get("UMB_SCHED", "auto")
         if config is None and not os.path.isdir(model_name) and state_dict is None:
             local = _resolve_hub_snapshot(model_name)             # HF cache, offline
@@ -202,7 +203,7 @@ class Llama(LLMBase):
             raise ValueError(f"Model type '{model_name}' is not supported. Supported types: {list(KNOWN.keys())} "
                              "or a local directory with config.json")
         if self.sched == "auto":
-            self.sched = "split" if self.config.awq else "ll"
+            self.sched = "split" if (self.config.awq or self.config.hidden_size >= 4096) else "ll"
         c = self.config
         if c.attention_bias:
             self.fused = False                    # projection bias: default / low-latency schedules only
