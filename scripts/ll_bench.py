@@ -22,6 +22,8 @@ SHAPES = {"70b": (torch.float16, 13, [("qkv", 10240, 8192, 1, 0), ("o", 8192, 81
                                     ("head", 128256, 2048, 0, 0)]),
           # balance experiment: 4096 n-tiles = 512 blocks = exactly 2 per CU (the real gate/up has 3584 = 448 blocks)
           "bal": (torch.float16, 13, [("gu", 57344, 8192, 1, 1), ("gu", 65536, 8192, 1, 1), ("gu", 49152, 8192, 1, 1)]),
+          # fixed cost vs streaming slope: the same N at three K
+          "kscan": (torch.float16, 13, [("gu", 57344, 512, 1, 1), ("gu", 57344, 1024, 1, 1), ("gu", 57344, 2048, 1, 1), ("gu", 57344, 4096, 1, 1), ("gu", 57344, 8192, 1, 1), ("gu", 57344, 16384, 1, 1)]),
           "8b": (torch.bfloat16, 31, [("qkv", 6144, 4096, 0, 0), ("o", 4096, 4096, 0, 0), ("gu", 28672, 4096, 0, 1), ("down", 4096, 14336, 0, 0)])}
 
 
@@ -70,6 +72,9 @@ def bench_shapes(model):
                 S_eff = cap
 
         R_old = int(os.environ.get("R_OLD", ln.R))
+        if os.environ.get("S_OLD") and epi_old == 0:
+            S_eff = int(os.environ["S_OLD"])
+            part = torch.empty(max(S_eff * T * N, 1), dtype=torch.float32, device=dev)
 
         def old(i):
             l = lins[i % ncopy]
@@ -148,7 +153,7 @@ def bench_stream():
     sink = torch.zeros(1, dtype=torch.int32, device=dev)
     us = timeit(lambda i: _lib.call("umb_stream_read", buf, buf.numel(), sink), reps=10, warm=2)
     print(f"stream read 2 GiB: {us:.1f} us -> {buf.numel()/us/1e3:.0f} GB/s", flush=True)
-    for mb in (33, 67, 235, 470):
+    for mb in (int(x) for x in os.environ.get("STREAM_MB", "33,67,235,470").split(",")):
         n = mb * 1000 * 1000 // 16 * 16
         k = min(buf.numel() // n, 8)
         us = timeit(lambda i: _lib.call("umb_stream_read", buf[(i % k) * n:], n, sink), reps=40, warm=4)

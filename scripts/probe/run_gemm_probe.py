@@ -12,7 +12,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 lib = C.CDLL(so)
 lib.gprobe_launch.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
 dev = "cuda:0"
-tiles, kb = 3584, 64
+tiles, kb = 3584, int(os.environ.get("KB", 64))
 per = tiles * kb * 1024
 ncopy = 6
 w = torch.empty(ncopy * per, dtype=torch.uint8, device=dev).random_(0, 255)
@@ -40,8 +40,11 @@ def run(feat, r, cb):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 40
     what = " + ".join(v for k, v in NAMES.items() if feat & k) or "loads only"
-    print(f"feat={feat:2d} R={r} CB={cb}: {us:6.1f} us  {per/us/1e3:6.0f} GB/s   [{what}]", flush=True)
+    print(f"KB={kb:3d} feat={feat:2d} R={r} CB={cb}: {us:6.1f} us  {per/us/1e3:6.0f} GB/s   [{what}]", flush=True)
 
 
-for feat, r, cb in ((0, 2, 4), (13, 2, 4), (45, 2, 4), (47, 2, 4), (77, 2, 4), (109, 2, 4), (205, 2, 4), (237, 2, 4), (237, 1, 4)):
+CASES = ((0, 2, 4), (13, 2, 4), (45, 2, 4), (47, 2, 4), (77, 2, 4), (109, 2, 4), (205, 2, 4), (237, 2, 4), (237, 1, 4))
+if os.environ.get("CASES"):
+    CASES = tuple(tuple(int(v) for v in c.split(":")) for c in os.environ["CASES"].split(","))
+for feat, r, cb in CASES:
     run(feat, r, cb)
