@@ -431,7 +431,8 @@ def run_tp_bench(args, wl, dtype, device, rank, world):
                           "2 RCCL all-reduces of [T, H] fp32 per layer", "tree": "3x4", "prompt_len": args.prompt_len},
                "accept_len": round(tokens / args.steps, 3)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():                                  # also the 1-rank group bench.py opens for the RCCL smoke run
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
     return out
