@@ -43,6 +43,8 @@ def run(u, lpp, bar, valu, lds):
 for lds in (0, 40 << 10, 80 << 10):
     for u, lpp in ((4, 1), (8, 1), (16, 1), (4, 2), (8, 2), (16, 2)):
         run(u, lpp, 0, 0, lds)
+if os.environ.get("ONLY_PLAIN"):      # per-CU rate experiments: TILES / NP choose how many CUs get a block
+    sys.exit(0)
 # valu: each unit is 3 full-rate VALU ops per dword; the exact int4 dequant is 13 per dword -> valu = 4; 7 = 21 per dword
 for cfg in ((8, 2, 1, 0), (8, 1, 1, 0), (8, 2, 0, 4), (8, 2, 1, 4), (8, 2, 0, 7), (8, 2, 1, 7), (8, 1, 0, 4), (8, 1, 0, 7),
             (16, 1, 0, 4), (16, 1, 1, 7), (16, 1, 0, 7), (4, 2, 0, 7)):

@@ -105,10 +105,11 @@ __global__ void repack_awq_kernel(const unsigned* __restrict__ qweight, const un
 // fragments of a CB x 128-k chunk are staged ONCE per block in LDS in fragment (lane-linear) order
 // -> conflict-free ds_read_b128, 4x less L2->L1 traffic than per-wave loads (the int4 path reads
 // 4 KiB of activations per 1 KiB weight tile, so unshared B loads were the bottleneck).
-// Weight tiles go straight from HBM to VGPRs (non-temporal), double buffered across 128-k blocks.
-// AWQ modes: 0 dense 16-bit weights; 1 int4, dequant folded out of the MFMA (any activation dtype);
-// 2 int4 with exact fp16 dequant in registers, W = fp16((q - z) * s) -- bit-identical to what
-// awq_ext.dequantize_weights_cuda produces -- via v_pk_add_f16 / v_pk_mul_f16 (fp16 activations only).
+// Weight tiles go straight from HBM to VGPRs (non-temporal buffer loads, a ring of 2 chunks); int4 metadata rides one
+// half-wave load per chunk through a wave-private LDS slot.  No load of the main loop is predicated (see the kernel).
+// AWQ modes: 0 dense 16-bit weights; 1 int4, dequant folded out of the MFMA (any activation dtype; the default for
+// launches of <= 64 rows); 2 int4 with exact fp16 dequant in registers, W = fp16((q - z) * s) -- bit-identical to what
+// awq_ext.dequantize_weights_cuda produces -- via v_pk_add_f16 / v_pk_mul_f16 (fp16 activations; wide launches).
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 // (a & mask) | magic in ONE VALU op.  gfx9 VOP3 may read a single SGPR/constant, so hipcc splits the pattern into
@@ -124,52 +125,6 @@ template <typename P, int AWQ, int R> struct Stage {
   u32x4 m4[AWQ == 1 ? R : 1];     // folded path: 4 x {scale, zero} for output rows g*4 .. g*4+3
   unsigned m1[AWQ == 2 ? R : 1];  // exact path : {scale, zero} of this lane's weight row
 };
-
-// Wave-uniform base pointers of one wave's weight stream (kept in SGPRs): the loads then use the
-// saddr + 32-bit lane offset form and need no per-load 64-bit VALU address arithmetic.
-template <int AWQ, int R> struct WaveBase {
-  const u32x4* w[R];              // tile stream of n-tile r at k-block 0
-  const unsigned char* m[R];      // AWQ metadata stream
-  long wstep, mstep;              // per 128-k block, in elements of the pointer type
-};
-
-template <int AWQ, int R>
-__device__ __forceinline__ WaveBase<AWQ, R> wave_base(const u32x4* wp, const unsigned char* meta, int nt0, int KB) {
-  WaveBase<AWQ, R> b;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int nt = nt0 + r;
-    if (AWQ) {
-      const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);       // tile order [N/64][K/128][4]
-      b.w[r] = wp + tile0 * 64;
-      b.m[r] = meta + tile0 * 64;
-    } else {
-      b.w[r] = wp + ((long)nt * KB) * 256;                             // 4 tiles (128 k) contiguous per k-block
-      b.m[r] = nullptr;
-    }
-  }
-  b.wstep = AWQ ? 4 * 64 : 256;
-  b.mstep = 4 * 64;
-  return b;
-}
-
-template <typename P, int AWQ, int R>
-__device__ __forceinline__ void stage_load(Stage<P, AWQ, R>& st, const WaveBase<AWQ, R>& wb, int kb, int lane) {
-  const int g = lane >> 4, i = lane & 15;
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const u32x4* w = wb.w[r] + (long)kb * wb.wstep;                    // uniform
-    if (AWQ) {
-      st.a[r][0] = __builtin_nontemporal_load(w + lane);
-      const unsigned char* m = wb.m[r] + (long)kb * wb.mstep;          // uniform
-      if (AWQ == 1) st.m4[r] = *reinterpret_cast<const u32x4*>(m + g * 16);
-      else st.m1[r] = *reinterpret_cast<const unsigned*>(m + i * 4);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) st.a[r][s] = __builtin_nontemporal_load(w + s * 64 + lane);
-    }
-  }
-}
 
 // xf: LDS fragments of this 128-k block, index (tt*4 + s)*64 + lane.
 // The weight fragments are built once per 128-k block (dequant for int4), then applied to every token tile:
