@@ -162,8 +162,63 @@ def bench_stream():
         print(f"stream read {mb} MB launches (SAME region, Infinity Cache resident if it fits): {us:.1f} us -> {n/us/1e3:.0f} GB/s", flush=True)
 
 
+def bench_graphscan():
+    """In-graph cost of one dependent launch vs K: 24 launches of the 70B gate/up GEMM (each reading the previous one's
+    output buffer as nothing -- the dependency is the stream order) captured in one hipGraph, weights rotated; the same
+    for umb_stream_read over the same bytes.  Fits time = fixed + bytes / rate for both."""
+    dtype, T, N = torch.float16, 13, 57344
+    dt = _lib.dtype_code(dtype)
+    sink = torch.zeros(1, dtype=torch.int32, device=dev)
+    rows = []
+    for K in (1024, 2048, 4096, 8192):
+        per = N * K // 2 + (N // 16) * (K // 128) * 64
+        ncopy = max(3, int(600e6 // per) + 1)
+        lins = [PackedLinear.from_awq(*synth_awq_tensors(N, K, 128, dev, gen), interleave=True) for _ in range(ncopy)]
+        x = torch.randn(T, K, device=dev).to(dtype)
+        act = torch.zeros(T, N // 2, dtype=dtype, device=dev)
+        nl = 24
+
+        def gemms():
+            for i in range(nl):
+                l = lins[i % ncopy]
+                _lib.call("umb_gemm", act, x, K, l.w, l.meta, T, N, K, l.awq, 1, l.R, 2, dt)
+
+        def reads():
+            for i in range(nl):
+                l = lins[i % ncopy]
+                _lib.call("umb_stream_read", l.w, l.w.numel() * l.w.element_size(), sink)
+
+        res = []
+        for fn in (gemms, reads):
+            s_ = torch.cuda.Stream()
+            with torch.cuda.stream(s_):
+                fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            res.append((time.time() - t0) / 20 / nl * 1e6)
+        rows.append((K, per, res[0], res[1]))
+        print(f"graph K={K:5d} {per/1e6:6.1f} MB: gemm {res[0]:6.2f} us/launch | stream read {res[1]:6.2f} us/launch", flush=True)
+        del lins
+        torch.cuda.empty_cache()
+    (k0, b0, g0, r0), (k1, b1, g1, r1) = rows[1], rows[3]
+    for name, a, b in (("gemm", g0, g1), ("read", r0, r1)):
+        slope = (b - a) / (b1 - b0)
+        print(f"{name}: fixed {a - slope * b0:5.2f} us + bytes / {1 / slope / 1e6:5.2f} TB/s", flush=True)
+
+
 for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
-    if what == "stream":
+    if what == "graphscan":
+        bench_graphscan()
+    elif what == "stream":
         bench_stream()
     elif what in SHAPES:
         bench_shapes(what)
