@@ -1048,11 +1048,16 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     if (fx.slot) fx.slot += t0;
     if (fx.q_out) fx.q_out += (long)t0 * fx.Hq * fx.D;
     int rc;
+    // k-blocks per LDS chunk (= half the weight ring) by token tiles.  Fewer = fewer registers = more waves per SIMD;
+    // measured optima below (UMB_CB / UMB_CB2 / UMB_CB4 override: experiments)
     static const int cb1 = getenv("UMB_CB") ? atoi(getenv("UMB_CB")) : UMB_CB1;
-    if (tn <= 16 && cb1 == 2) rc = launch_r<P, AWQ, 1, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
-    else if (tn <= 16) rc = launch_r<P, AWQ, 1, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
-    else if (tn <= 32) rc = launch_r<P, AWQ, 2, 4>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
-    else rc = launch_r<P, AWQ, 4, 2>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st);
+    static const int cb2 = getenv("UMB_CB2") ? atoi(getenv("UMB_CB2")) : 1;      // 16 layers of the 70B at T = 31: 3.50 (CB 4) / 2.79 / 2.78 ms
+    static const int cb4 = getenv("UMB_CB4") ? atoi(getenv("UMB_CB4")) : 1;      // T = 64: 4.96 (CB 2) / 4.60 ms
+#define UMB_LR(TTV, CBV) rc = launch_r<P, AWQ, TTV, CBV>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st)
+    if (tn <= 16) { if (cb1 == 1) UMB_LR(1, 1); else if (cb1 == 2) UMB_LR(1, 2); else UMB_LR(1, 4); }
+    else if (tn <= 32) { if (cb2 == 1) UMB_LR(2, 1); else if (cb2 == 2) UMB_LR(2, 2); else UMB_LR(2, 4); }
+    else { if (cb4 == 1) UMB_LR(4, 1); else UMB_LR(4, 2); }
+#undef UMB_LR
     if (rc) return rc;
   }
   return UMB_OK;
