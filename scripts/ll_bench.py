@@ -223,9 +223,10 @@ for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
     elif what in SHAPES:
         bench_shapes(what)
     elif what == "fwd1b":
-        for T in (1, 3):
+        for T in (int(v) for v in os.environ.get("T1B", "1,3").split(",")):
             bench_forward("meta-llama/Llama-3.2-1B-Instruct", 16, T, torch.float16)
     elif what == "fwd70b":
         bench_forward("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", 16, int(os.environ.get("T70", 13)), torch.float16)
     elif what == "fwd8b":
-        bench_forward("meta-llama/Llama-3.1-8B-Instruct", 32, 31, torch.bfloat16)
+        for T in (int(v) for v in os.environ.get("T8B", "31").split(",")):
+            bench_forward("meta-llama/Llama-3.1-8B-Instruct", 32, T, torch.bfloat16)
