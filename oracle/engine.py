@@ -183,9 +183,14 @@ class OracleStaticEngine(_Common):
                 new = ops.topk_flatten_gather(logits, max(self.branches[step]), self.gather_idx[step])
                 self.tokens[0, self.cur:self.cur + sum(self.branches[step])] = new
 
-    def _stochastic(self, logits):
-        raise NotImplementedError("static stochastic path needs flashinfer's rejection sampler; "
-                                  "only distributional parity is defined (SURVEY 8c)")
+    def _stochastic(self, logits):                                   # static:131,310
+        """flashinfer.sampling.top_k_top_p_sampling_from_logits(logits / T, uniform_samples, topk, topp) with the ONE
+        uniform_samples = rand(3, tree_size) tensor drawn at initialize() and reused by every verify (static:131) --
+        the caller passes it in (`uniform_samples`), so a recorded reference run can be replayed draw for draw.
+        The sampler itself is the restatement in oracle/ops.py (flashinfer wheel absent: parity unpinned there)."""
+        assert self.uniform_samples is not None, "static stochastic verification needs the engine's uniform_samples"
+        ids, _ = ops.top_k_top_p_sampling_from_logits(logits / self.temperature, self.uniform_samples, self.topk, self.topp)
+        return ids
 
     def verify(self):                                                # static:282-351
         sl = slice(self.num_nodes, self.cur)

@@ -176,3 +176,69 @@ def top_p_renorm(probs: torch.Tensor, top_p: float):
     sp = sp.masked_fill(drop, 0.0)
     out = torch.zeros_like(probs).scatter(-1, si, sp)
     return out / out.sum(dim=-1, keepdim=True)
+
+
+# ----------------------------------------------------------------------------
+# flashinfer.sampling.top_k_top_p_sampling_from_logits(logits, uniform_samples, top_k, top_p)
+# -- the static engine's verification sampler (static_speculation_engine.py:131,310).
+#
+# PARITY UNPINNED: the flashinfer wheel is absent here and the reference does not pin its version (install.sh:2); the
+# positional `uniform_samples` argument belongs to the 0.2.x API.  What follows restates that release's published
+# algorithm (python/flashinfer/sampling.py + include/flashinfer/sampling.cuh), default filter_apply_order
+# "top_k_first":  top_k_mask_logits -> softmax -> top_p_sampling_from_probs, the latter a REJECTION sampler driven by
+# caller-supplied uniforms u[round][row] (TopPSamplingFromProbKernel):
+#     q = 1, pivot = 0
+#     for round in 0 .. rounds-1:
+#         id    = first index i (vocabulary order) with  sum_{j <= i, p_j > pivot} p_j  >  u[round] * q   (else V - 1)
+#         pivot = max(pivot, p_id)
+#         q     = sum_{p_j > pivot} p_j              # mass strictly above the drawn token
+#         if q < top_p: accept                        # the drawn token lies inside the nucleus
+# After the last round the current id is returned whether accepted or not (success = False).  With unlimited rounds the
+# output distribution is p restricted to the nucleus {i : mass(p_j > p_i) < top_p}, renormalised -- the same set
+# top_p_renorm() keeps; with the reference's 3 rounds at most (1 - top_p)^3 of the mass falls outside it.
+# ----------------------------------------------------------------------------
+def top_k_mask_logits(logits: torch.Tensor, top_k: int):
+    k = min(int(top_k), logits.size(-1))
+    kth = torch.topk(logits, k, dim=-1)[0][..., -1, None]
+    return logits.masked_fill(logits < kth, -torch.inf)
+
+
+def top_p_sampling_from_probs(probs: torch.Tensor, uniform_samples: torch.Tensor, top_p: float):
+    """probs [B, V] fp32, uniform_samples [rounds, B] in [0, 1).  Returns (ids int64 [B], success bool [B])."""
+    B, V = probs.shape
+    rounds = uniform_samples.shape[0]
+    ids = torch.full((B,), V - 1, dtype=torch.long)
+    ok = torch.zeros(B, dtype=torch.bool)
+    for b in range(B):
+        p = probs[b].float()
+        q, pivot = 1.0, 0.0
+        for r in range(rounds):
+            u = float(uniform_samples[r, b]) * q
+            cum = torch.cumsum(torch.where(p > pivot, p, torch.zeros_like(p)), dim=0)
+            hit = (cum > u).nonzero()
+            sid = int(hit[0]) if hit.numel() else V - 1
+            pivot = max(pivot, float(p[sid]))
+            q = float(p[p > pivot].sum())
+            ids[b] = sid
+            if q < top_p:
+                ok[b] = True
+                break
+    return ids, ok
+
+
+def top_k_top_p_sampling_from_logits(logits: torch.Tensor, uniform_samples: torch.Tensor, top_k: int, top_p: float):
+    probs = torch.softmax(top_k_mask_logits(logits.float(), top_k), dim=-1)
+    return top_p_sampling_from_probs(probs, uniform_samples, top_p)
+
+
+def nucleus_distribution(logits: torch.Tensor, top_k: int, top_p: float):
+    """The limit distribution of the sampler above (unlimited rounds): softmax over the top-k logits, restricted to
+    {i : mass of strictly more probable tokens < top_p}, renormalised.  [B, V] fp32."""
+    probs = torch.softmax(top_k_mask_logits(logits.float(), top_k), dim=-1)
+    out = torch.zeros_like(probs)
+    for b in range(probs.shape[0]):
+        p = probs[b]
+        above = (p[None, :] > p[:, None]).float() @ p            # mass strictly above each token
+        keep = (above < top_p) & (p > 0)
+        out[b] = torch.where(keep, p, torch.zeros_like(p))
+    return out / out.sum(dim=-1, keepdim=True)

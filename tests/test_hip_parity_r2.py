@@ -165,6 +165,16 @@ def _compare_with_golden(got, gold, margins, tol):
     return same
 
 
+def _require_full_or_flagged(got, gold, margins, tol):
+    """The whole recorded sequence must be reproduced; the only accepted exit is a divergence at a position whose fp32
+    margin lies inside the 16-bit noise band (_compare_with_golden asserts that), never a short common prefix."""
+    same = _compare_with_golden(got, gold, margins, tol)
+    diverged = same < min(len(got), len(gold))
+    if not diverged:
+        assert len(got) == len(gold) == same, (len(got), len(gold), same)
+    return same, diverged
+
+
 STATIC_CASES = ["static_3x4", "static_3x4_selfdraft", "static_5x6_selfdraft", "static_3x4_exit2",
                 "static_3x4_selfdraft_eos"]
 DYNAMIC_CASES = ["dynamic_w4b6d3", "dynamic_w8b8d4_selfdraft", "dynamic_w8b8d4_selfdraft_eos"]
@@ -192,11 +202,8 @@ def test_engines_replay_reference_token_sequences(dev, case_name):
     got = out["generated_tokens"]
     margins, _ = _margins(sd, case["prompt"] + gold, len(case["prompt"]),
                           first_eos_mask=case["eos"] if c["engine"] == "dynamic" else None)
-    same = _compare_with_golden(got, gold, margins, TOL[dtype])
-    assert same >= min(6, len(gold)), (same, len(gold))
-    if same == len(gold) == len(got):
-        # identical sequence: an EOS-terminated case must also stop at the same place
-        assert len(got) == len(gold)
+    # identical sequence (an EOS-terminated case stops at the same place) unless a margin-flagged near-tie is found
+    _require_full_or_flagged(got, gold, margins, TOL[dtype])
 
 
 def test_static_two_turn_trace_replay(dev):
@@ -230,9 +237,12 @@ def test_static_two_turn_trace_replay(dev):
     if ok:
         assert steps == turn["steps"]
         assert eng._append(torch.tensor([case["append"]])) == case["append_ok"]
-        assert int(eng.tokens[eng.num_nodes]) == case["append_first_token"] or True   # margin-checked below
         ctx = eng.tokens[:eng.num_nodes].tolist()
         assert ctx == case["prompt"] + turn["tokens"] + case["append"]
+        first = int(eng.tokens[eng.num_nodes])
+        if first != case["append_first_token"]:                 # only a 16-bit near-tie may move the first token of turn 2
+            m2, _ = _margins(sd, ctx + [case["append_first_token"]], len(ctx))
+            assert m2[0] < 2 * TOL[dtype], (first, case["append_first_token"], m2[0])
 
 
 # ------------------------------------------------------------------ AWQ x offload x dynamic (BASELINE config 3's path)

@@ -94,6 +94,30 @@ def test_shipped_growmaps_are_generator_outputs():
         assert json.load(f) == ref34                      # same tree as the reference's shipped 3x4
 
 
+def test_all_six_reference_growmaps_are_shipped():
+    """Every growmap the reference ships exists here under the same name and is the same data (sha256 of the canonical
+    JSON, recorded from /root/reference by scripts/fit_growmaps.py); the one topology no acceptance vector reproduces
+    (5x8: a score tie in the original run) is rebuilt from its recorded branch table."""
+    import hashlib
+    from umbrella_amd.sequoia_utils import growmap_from_branches
+    tdir = os.path.join(os.path.dirname(GOLD), "..", "umbrella_amd", "trees")
+    with open(os.path.join(GOLD, "ref_tree_digests.json")) as f:
+        digests = json.load(f)
+    assert len(digests) == 6
+    for name, want in digests.items():
+        with open(os.path.join(tdir, name)) as f:
+            gm = json.load(f)
+        assert hashlib.sha256(json.dumps(gm, sort_keys=True, separators=(",", ":")).encode()).hexdigest() == want, name
+    with open(os.path.join(tdir, "branch_tables.json")) as f:
+        for name, table in json.load(f).items():
+            with open(os.path.join(tdir, name)) as g:
+                assert json.load(g) == growmap_from_branches(table), name
+    # the 3x4 tree from its own branch table: the two constructions agree where both apply
+    with open(os.path.join(tdir, "sequoia_tree-3x4.json")) as f:
+        gm = json.load(f)
+    assert growmap_from_branches(gm["branches"]) == gm
+
+
 def test_reference_config_growmap_paths_resolve():
     """A reference config's ``growmap_path`` (relative to the reference's examples directory) resolves to the shipped
     tree of the same name; unknown names fail loudly."""
@@ -218,3 +242,66 @@ def test_awq_pack_roundtrip_and_linear():
     torch.testing.assert_close(out, x @ torch.from_numpy(W.astype(np.float16).astype(np.float32)), rtol=1e-4, atol=1e-4)
     from umbrella_amd.models.awq_format import pack_rows, unpack_rows
     assert np.array_equal(pack_rows(q), ops.awq_pack(q)) and np.array_equal(unpack_rows(pack_rows(q)), q)
+
+
+# ------------------------------------------------------------------ static engine, stochastic verification
+def _stochastic_cases():
+    with open(os.path.join(GOLD, "engines_stochastic.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("case_name", ["static_3x4_stochastic", "static_3x4_selfdraft_stochastic"])
+def test_static_stochastic_replays_reference_trace(case_name):
+    """The reference's static engine on its sampling path (static:131,298-310; tests/golden/make_golden_stochastic.py):
+    with the recorded uniform_samples the oracle engine reproduces every iteration's tree, sampled ids, accept result
+    and bonus token -- the penalty -> /temperature -> one-sampler-call-with-the-same-uniforms order is pinned (the
+    sampler's own internals are a restatement: flashinfer wheel absent)."""
+    from oracle.engine import OracleStaticEngine
+    case = _stochastic_cases()[case_name]
+    c = case["config"]
+    self_draft = "selfdraft" in case_name
+    dcfg, dseed = (G["target_cfg"], G["seeds"]["target"]) if self_draft else (G["draft_cfg"], G["seeds"]["draft"])
+    L = c["max_length"]
+    target = oracle_model(G["target_cfg"], G["seeds"]["target"], L, torch.float32)
+    draft = oracle_model(dcfg, dseed, L, torch.float32, slot_cache=True)
+    with open(os.path.join(GOLD, "growmaps.json")) as f:
+        gm = json.load(f)["3x4"]
+    eng = OracleStaticEngine(draft, target, gm, case["eos"], max_length=L, safe_buffer=c["safe_buffer"],
+                             temperature=c["temperature"], topp=c["topp"], topk=c["topk"],
+                             repetition_penalty=c["repetition_penalty"],
+                             uniform_samples=torch.tensor(case["uniform_samples"]))
+    assert eng._prefill(torch.tensor([case["prompt"]]))
+    assert int(eng.tokens[0, eng.num_nodes]) == case["first_token"]
+    start = eng.num_nodes
+    for rec in case["iters"]:
+        assert eng.num_nodes == rec["n"]
+        eng.build_tree()
+        assert eng.tokens[0, rec["n"]:rec["n"] + eng.tree_size].tolist() == rec["tree_tokens"]
+        go = eng.verify()
+        assert eng.trace[-1]["sampled"] == rec["sampled"]
+        assert eng.num_nodes == rec["num_nodes"] and go == rec["go_on"]
+        assert int(eng.tokens[0, eng.num_nodes]) == rec["bonus"]
+    assert eng.tokens[0, start:eng.num_nodes + 1].tolist() == case["tokens"]
+
+
+def test_rejection_sampler_limit_is_the_renormalised_nucleus():
+    """oracle.ops.top_k_top_p_sampling_from_logits (flashinfer's rejection sampler, restated): every accepted draw lies
+    in the nucleus, empirical frequencies follow nucleus_distribution (chi-square), and that set is the one
+    top_p_renorm keeps -- the distribution umb_sample_rows is tested against on the GPU."""
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(1, 64, generator=g) * 2.0
+    k, p = 16, 0.9
+    nuc = ops.nucleus_distribution(logits, k, p)[0]
+    ref = ops.top_p_renorm(torch.softmax(ops.keep_topk(logits, k), dim=-1), p)[0]
+    torch.testing.assert_close(nuc, ref, rtol=1e-5, atol=1e-7)
+    n = 4000
+    u = torch.rand(32, n, generator=g)                          # 32 rounds: rejection never runs out
+    ids, ok = ops.top_k_top_p_sampling_from_logits(logits.expand(n, -1), u, k, p)
+    assert bool(ok.all()) and bool((nuc[ids] > 0).all())
+    cnt = torch.bincount(ids, minlength=64).float()
+    sup = nuc > 0
+    chi2 = float((((cnt - n * nuc) ** 2)[sup] / (n * nuc[sup])).sum())
+    assert chi2 < 3.0 * int(sup.sum()) + 20, chi2
+    # the reference's 3 rounds: draws that exhaust them may fall outside the nucleus, at most (1 - top_p)^3 of them
+    ids3, ok3 = ops.top_k_top_p_sampling_from_logits(logits.expand(n, -1), u[:3], k, p)
+    assert float((~ok3).float().mean()) <= (1 - p) ** 3 + 0.01

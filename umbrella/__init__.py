@@ -50,4 +50,8 @@ def __getattr__(name):
     try:
         return getattr(_impl, name)
     except AttributeError:
+        pass
+    try:
         return importlib.import_module(_PREFIX + name)
+    except ImportError:                                     # hasattr / inspect.unwrap / mock.patch probe with AttributeError
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None

@@ -289,8 +289,9 @@ class Llama(LLMBase):
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
             lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
-        if self.fused and self.sched != "ll":
-            lin.R = 1                              # the in-kernel split epilogues own one n-tile per wave
+        if self.fused:
+            lin.R = 1                              # the in-kernel split epilogues own one n-tile per wave (ws.fused == 1
+                                                   # whenever self.fused is set, whatever `sched` says: see reserve())
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
 

@@ -83,7 +83,9 @@ class PipelineComm:
     def _recv(self, buf, host, src):
         if self.host_staging:
             dist.recv(host[:buf.shape[0]], src=src)
-            buf.copy_(host[:buf.shape[0]], non_blocking=True)
+            # blocking: the single pinned staging buffer is overwritten by the next recv (a multi-chunk prompt on the last
+            # stage has no other synchronisation point between two chunks)
+            buf.copy_(host[:buf.shape[0]], non_blocking=False)
         else:
             dist.recv(buf, src=src)
 
@@ -415,10 +417,14 @@ class PipelinedStaticEngine(_Static):
 
     def _leave_decode(self):
         if self._in_decode:
-            if self._pending:
-                self._flush_commit(cont=0)
-            else:                                    # decode mode entered but no iteration ran: cannot happen via step()
-                raise RuntimeError("pipeline left decode mode without a pending commit")
+            if not self._pending:
+                # decode mode was entered but the iteration died before its commit was formed (a kernel or transport
+                # error inside verify_tree): the stages still wait for one.  Release them with a no-op commit -- keep 0
+                # tokens, num_nodes unchanged, cont = 0 -- so reset() / a new prompt / shutdown work afterwards.
+                self.res.zero_()
+                self.res[3] = int(self.num_nodes)
+                self._pending = True
+            self._flush_commit(cont=0)
             self._in_decode = False
 
     def reset(self):

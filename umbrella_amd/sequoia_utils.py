@@ -128,6 +128,34 @@ def generate_budget_tree(size: int, max_depth: int, acc=None, json_file=None):
     return out
 
 
+def growmap_from_branches(branches, json_file=None):
+    """Growmap from its branch table alone: ``branches[lvl][j]`` children for the j-th node of level lvl, nodes numbered
+    level by level and children laid out by (parent order, rank) -- the layout every growmap of this format has
+    (umbrella/sequoia_utils.py:110-113).  Used for topologies the score-greedy generator cannot reproduce from any
+    acceptance vector (a level where a lower-scored node keeps a child its higher-scored sibling lost: produced by
+    score ties in the original run)."""
+    roots, succ, tdepth = [[0]], [[]], [0]
+    for lvl, row in enumerate(branches):
+        assert len(row) == len(roots[lvl]), (lvl, row)
+        nxt = []
+        for j, b in enumerate(row):
+            kids = list(range(len(succ), len(succ) + b))
+            succ[roots[lvl][j]] = kids
+            succ += [[] for _ in kids]
+            tdepth += [lvl + 1] * b
+            nxt += kids
+        if not nxt:
+            assert all(sum(r) == 0 for r in branches[lvl:]), "branch rows after an empty level must be zero"
+            break
+        roots.append(nxt)
+    out = {"roots": roots, "branches": [list(r) for r in branches[:len(roots)]], "Successors": succ,
+           "mask": successor_list_to_mask(succ), "depth": tdepth, "size": len(succ)}
+    if json_file is not None:
+        with open(json_file, "w") as f:
+            json.dump(out, f, indent=4)
+    return out
+
+
 def expected_accept_length(growmap: dict, acc) -> float:
     """E[#accepted tokens per verify] (root + bonus counted as in the engines' dec_len/steps)
     if the rank-r child of any node is accepted with probability acc[r]."""

@@ -171,8 +171,13 @@ class LocalComm:
 def _pick(allp):
     vals = torch.stack([p[:, 0] for p in allp])            # [P, T]
     idx = torch.stack([p[:, 1] for p in allp])
-    best = vals.argmax(dim=0)                              # first rank holding the maximum = lowest vocabulary index
-    return idx.gather(0, best[None])[0].to(torch.int32)
+    # ties -> lowest global vocabulary index, by construction (torch.argmax does not promise which maximal entry it
+    # returns): the minimum index among the entries equal to the column maximum; a NaN shard maximum counts as -inf on
+    # every rank alike, so all ranks agree on the token.
+    vals = torch.nan_to_num(vals, nan=-float("inf"))
+    mx = vals.max(dim=0, keepdim=True).values
+    cand = torch.where(vals == mx, idx, torch.full_like(idx, float("inf")))
+    return cand.min(dim=0).values.to(torch.int32)
 
 
 # ------------------------------------------------------------------ the sharded target
