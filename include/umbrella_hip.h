@@ -138,6 +138,25 @@ int umb_reduce_qkv_rope2(const void* partial, int S, int T, int Hq, int Hkv, int
                          const int* slot, const void* cosT, const void* sinT, void* q_out, void* k_cache,
                          void* vt_cache, int paired, const void* bias, const float* ssq_in, int ssq_groups,
                          int ssq_stride, float ssq_dim, float eps, int dtype, umb_stream_t stream);
+/* Stand-alone forms on 16-bit tensors, for an integrator who replaces the reference call site by call site
+ * (INTEGRATION.md option B) instead of adopting the fused layer chain:
+ * apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) in place at positions pos[t]: q [T][Hq][D] and
+ * k [T][Hkv][D] when layout == 0 (NHD, the reference's [1, T, H, D] tensors), [H][T][D] when layout == 1;
+ * x * cos + rotate_half(x) * sin in the model dtype (each product and the sum rounded, as eager torch does).
+ * cosT / sinT: [Lmax][D] model dtype (llama.py:48-60).  Either of q / k may be NULL with its head count 0. */
+int umb_rope_inplace(void* q, void* k, const void* cosT, const void* sinT, const int* pos, int T, int Hq, int Hkv,
+                     int D, int layout, int dtype, umb_stream_t stream);
+/* KV_Cache.update_kv_cache / StaticKV_Cache index_copy_ (umbrella/attn/cache.py:53-65, 155-156): k, v [T][Hkv][D]
+ * 16-bit -> K cache [Hkv][Lmax][D] at rows slot[t], V cache transposed [Hkv][D][Lmax + UMB_VT_PAD] at columns slot[t]
+ * (layer base pointers).  Slots outside [0, Lmax) are dropped. */
+int umb_kv_append(void* k_cache, void* vt_cache, const void* k, const void* v, const int* slot, int T, int Hkv, int D,
+                  int Lmax, int dtype, umb_stream_t stream);
+/* LlamaAwqLayer.copy / LlamaLayer.copy (umbrella/models/llama_layer.py:244-258, 23 small copies per layer there): ONE
+ * hipMemcpyAsync of a whole layer slab from pinned host memory on `copy_stream`.  ev_free (hipEvent_t or NULL): the
+ * copy waits for it on copy_stream (record it on the compute stream behind the kernels that last read `dst`);
+ * ev_copied (hipEvent_t or NULL): recorded behind the copy (the compute stream waits for it before using `dst`). */
+int umb_h2d_layer(void* dst, const void* src_pinned, size_t bytes, umb_stream_t copy_stream, void* ev_free,
+                  void* ev_copied);
 /* F.embedding (llama.py:124) + per-forward position/slot/prefix resolution.
  * explicit mode: tok/pos/slot/prefix given.  tree mode (tokens_all != NULL):
  * token i = tokens_all[*n_ptr + off + i], position = *n_ptr + depth[off+i], slot = *n_ptr + off + i.

@@ -681,3 +681,80 @@ def test_verify_gemm_wide_full_width(dev, awq, T):
         wd = w[:128].float().t()
     ref = x.float() @ wd
     assert float((y[:, :128] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------ stand-alone 16-bit RoPE / KV append / slab copy (C-ABI completeness)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_rope_inplace_matches_oracle(dev, dtype, layout):
+    """umb_rope_inplace == apply_rotary_pos_emb (model_utils.py:17-52) on 16-bit q / k at tree positions: bit-exact
+    (every product and the sum rounded to the model dtype, as the reference's eager torch does)."""
+    from umbrella_amd import _lib
+    from umbrella_amd.models.config import LlamaCfg, rope_tables
+    T, Hq, Hkv, D, Lmax = 13, 8, 2, 128, 64
+    g = torch.Generator().manual_seed(3 + layout)
+    q = torch.randn(T, Hq, D, generator=g).to(dtype)
+    k = torch.randn(T, Hkv, D, generator=g).to(dtype)
+    pos = torch.tensor([9, 10, 10, 11, 11, 11, 12, 12, 12, 12, 13, 40, 63], dtype=torch.int32)
+    cos, sin = rope_tables(LlamaCfg(head_dim=D), Lmax, dtype)
+    qe, ke = O.apply_rope(q, k, cos, sin, pos.long())
+    qd = (q if layout == 0 else q.permute(1, 0, 2)).contiguous().to(dev)
+    kd = (k if layout == 0 else k.permute(1, 0, 2)).contiguous().to(dev)
+    _lib.call("umb_rope_inplace", qd, kd, cos.to(dev).contiguous(), sin.to(dev).contiguous(), pos.to(dev), T, Hq, Hkv, D,
+              layout, _lib.dtype_code(dtype))
+    got_q = qd.cpu() if layout == 0 else qd.cpu().permute(1, 0, 2)
+    got_k = kd.cpu() if layout == 0 else kd.cpu().permute(1, 0, 2)
+    assert torch.equal(got_q, qe) and torch.equal(got_k, ke)
+    # k only (q == NULL, Hq == 0)
+    kd2 = (k if layout == 0 else k.permute(1, 0, 2)).contiguous().to(dev)
+    _lib.call("umb_rope_inplace", None, kd2, cos.to(dev).contiguous(), sin.to(dev).contiguous(), pos.to(dev), T, 0, Hkv, D,
+              layout, _lib.dtype_code(dtype))
+    assert torch.equal(kd2, kd)
+    with pytest.raises(_lib.UmbError):
+        _lib.call("umb_rope_inplace", None, kd2, cos.to(dev), sin.to(dev), pos.to(dev), T, Hq, Hkv, D, layout, _lib.dtype_code(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kv_append_then_attention(dev, dtype):
+    """umb_kv_append places k / v rows at their slots of the K and V^T caches (cache.py:53-65,155-156); attention over
+    the appended cache equals the oracle's masked attention on the same keys."""
+    from umbrella_amd import _lib
+    T, Hq, Hkv, D, Lmax = 7, 4, 2, 64, 64
+    g = torch.Generator().manual_seed(5)
+    kc = torch.zeros(Hkv, Lmax, D, dtype=dtype, device=dev)
+    vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype, device=dev)
+    k = torch.randn(T, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(T, Hkv, D, generator=g).to(dtype)
+    slot = torch.tensor([9, 10, 11, 12, 13, 14, 70], dtype=torch.int32)            # the last slot is outside the cache: dropped
+    _lib.call("umb_kv_append", kc, vt, k.to(dev), v.to(dev), slot.to(dev), T, Hkv, D, Lmax, _lib.dtype_code(dtype))
+    kref = torch.zeros(Hkv, Lmax, D, dtype=dtype)
+    vref = torch.zeros(Hkv, Lmax, D, dtype=dtype)
+    for t in range(T - 1):
+        kref[:, int(slot[t])] = k[t]
+        vref[:, int(slot[t])] = v[t]
+    assert torch.equal(kc.cpu(), kref)
+    assert torch.equal(vt.cpu()[:, :, :Lmax], vref.permute(0, 2, 1))
+    assert float(vt[:, :, Lmax:].abs().max()) == 0.0
+
+
+def test_h2d_layer_event_ordered(dev):
+    """umb_h2d_layer: one pinned-host -> device slab copy on a side stream, ordered by (ev_free, ev_copied)."""
+    import ctypes as C
+    from umbrella_amd import _lib
+    lib = _lib.load()
+    n = 8 << 20
+    host = torch.randint(0, 255, (n,), dtype=torch.uint8).pin_memory()
+    dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    ev_free, ev_copied = torch.cuda.Event(), torch.cuda.Event()
+    dst.add_(1)                                                    # a kernel that still uses `dst` on the compute stream
+    ev_free.record()
+    ev_copied.record()
+    rc = lib.umb_h2d_layer(C.c_void_p(dst.data_ptr()), C.c_void_p(host.data_ptr()), C.c_size_t(n),
+                           C.c_void_p(side.cuda_stream), C.c_void_p(ev_free.cuda_event), C.c_void_p(ev_copied.cuda_event))
+    assert rc == 0
+    torch.cuda.current_stream().wait_event(ev_copied)
+    out = dst + 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), host)
+    assert lib.umb_h2d_layer(None, C.c_void_p(host.data_ptr()), C.c_size_t(n), C.c_void_p(side.cuda_stream), None, None) == -22

@@ -105,6 +105,9 @@ SIGNATURES = {
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
     "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "umb_stream_read": [_P, C.c_size_t, _P, _P],
+    "umb_rope_inplace": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "umb_kv_append": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "umb_h2d_layer": [_P, _P, C.c_size_t, _P, _P, _P],
     "umb_reduce_qkv_rope2": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _I, _P],
     "umb_embed_prep": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "umb_tree_attn": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],

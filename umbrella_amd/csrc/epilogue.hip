@@ -316,6 +316,48 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
   }
 }
 
+// ---- stand-alone 16-bit RoPE / KV append (per-call-site integration: the reference applies them to q / k / v tensors
+// in the model dtype, model_utils.py:17-52 and attn/cache.py:53-65; the fused forms above take fp32 split-K partials)
+// q [T][Hq][D] / k [T][Hkv][D] (layout 0, NHD: what apply_rotary_pos_emb sees as [1, T, H, D]) or [H][T][D] (layout 1),
+// rotated in place at pos[t]; one 64-lane block per (token, head), lane d handles the pair (d, d + D/2).
+template <typename P>
+__global__ __launch_bounds__(64) void rope_inplace_kernel(u16* __restrict__ q, u16* __restrict__ k,
+                                                          const u16* __restrict__ cosT, const u16* __restrict__ sinT,
+                                                          const int* __restrict__ pos, int T, int Hq, int Hkv, int D,
+                                                          int layout) {
+  const int t = blockIdx.x, head = blockIdx.y, half = D / 2;
+  const bool isq = head < Hq;
+  const int hh = isq ? head : head - Hq, H = isq ? Hq : Hkv;
+  u16* base = (isq ? q : k) + (layout == 0 ? ((long)t * H + hh) * D : ((long)hh * T + t) * D);
+  const long cb = (long)pos[t] * D;
+  for (int d = threadIdx.x; d < half; d += 64) {
+    const float a = P::to_f(base[d]), b = P::to_f(base[d + half]);
+    const float c0 = P::to_f(cosT[cb + d]), c1 = P::to_f(cosT[cb + d + half]);
+    const float s0 = P::to_f(sinT[cb + d]), s1 = P::to_f(sinT[cb + d + half]);
+    // x * cos + rotate_half(x) * sin in the model dtype: every product and the sum are rounded, as eager torch does
+    base[d] = P::from_f(rnd<P>(a * c0) + rnd<P>(-b * s0));
+    base[d + half] = P::from_f(rnd<P>(b * c1) + rnd<P>(a * s1));
+  }
+}
+
+// k / v [T][Hkv][D] -> K cache [Hkv][Lmax][D] row slot[t], V^T cache [Hkv][D][Lmax + UMB_VT_PAD] column slot[t]
+__global__ __launch_bounds__(64) void kv_append_kernel(u16* __restrict__ kc, u16* __restrict__ vt,
+                                                       const u16* __restrict__ k, const u16* __restrict__ v,
+                                                       const int* __restrict__ slot, int Hkv, int D, int Lmax) {
+  const int t = blockIdx.x, h = blockIdx.y;
+  const int sl = slot[t];
+  if (sl < 0 || sl >= Lmax) return;                               // a slot outside the cache is dropped, never written
+  const long LV = VT_LD(Lmax);
+  const u16* ks = k + ((long)t * Hkv + h) * D;
+  const u16* vs = v + ((long)t * Hkv + h) * D;
+  u16* kd = kc + ((long)h * Lmax + sl) * D;
+  u16* vd = vt + (long)h * D * LV + sl;
+  for (int d = threadIdx.x; d < D; d += 64) {
+    kd[d] = ks[d];
+    vd[(long)d * LV] = vs[d];
+  }
+}
+
 // ------------------------------------------------------------------ C entry points
 extern "C" int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype,
                            hipStream_t st) {
@@ -383,5 +425,37 @@ extern "C" int umb_embed_prep(void* x, const void* table, int H, int T, const in
                        (const u16*)norm_w, ssq, ssq_stride);
   })
   UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_rope_inplace(void* q, void* k, const void* cosT, const void* sinT, const int* pos, int T, int Hq,
+                                int Hkv, int D, int layout, int dtype, hipStream_t st) {
+  if (T < 1 || D % 2 || Hq < 0 || Hkv < 0 || Hq + Hkv < 1 || (layout != 0 && layout != 1) || (Hq && !q) || (Hkv && !k))
+    return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((rope_inplace_kernel<P>), dim3(T, Hq + Hkv), dim3(64), 0, st, (u16*)q, (u16*)k, (const u16*)cosT,
+                       (const u16*)sinT, pos, T, Hq, Hkv, D, layout);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_kv_append(void* k_cache, void* vt_cache, const void* k, const void* v, const int* slot, int T,
+                             int Hkv, int D, int Lmax, int dtype, hipStream_t st) {
+  if (T < 1 || Hkv < 1 || D < 1 || Lmax < 1 || (dtype != UMB_F16 && dtype != UMB_BF16)) return UMB_EINVAL;
+  hipLaunchKernelGGL(kv_append_kernel, dim3(T, Hkv), dim3(64), 0, st, (u16*)k_cache, (u16*)vt_cache, (const u16*)k,
+                     (const u16*)v, slot, Hkv, D, Lmax);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+// one layer slab, pinned host -> device, on the copy stream; event ordered against the compute stream: the slab may be
+// overwritten only after ev_free (recorded by the caller behind the kernels that read it), and ev_copied marks arrival
+extern "C" int umb_h2d_layer(void* dst, const void* src_pinned, size_t bytes, hipStream_t copy_stream, void* ev_free,
+                             void* ev_copied) {
+  if (!dst || !src_pinned || bytes == 0) return UMB_EINVAL;
+  if (ev_free && hipStreamWaitEvent(copy_stream, (hipEvent_t)ev_free, 0) != hipSuccess) return UMB_EHIP;
+  if (hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, copy_stream) != hipSuccess) return UMB_EHIP;
+  if (ev_copied && hipEventRecord((hipEvent_t)ev_copied, copy_stream) != hipSuccess) return UMB_EHIP;
   return UMB_OK;
 }
