@@ -17,10 +17,19 @@ DEFAULT_ACC vector, umbrella/sequoia_utils.py:7).  Every draft / verify kernel s
 `accept_len` is reported next to the value, and `value_raw_draft` is the same loop with the
 knob off (accept ~1.0).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): independent requests, one engine
-replica per GPU, no data-path collective ("scaling": "weak"); the timed region is bracketed by
-barriers and the max over ranks is used.  `--parallel pp` instead shards the target's layers
-across the ranks (RCCL send/recv of the [T, H] activations, BASELINE config 5).
+N = 1 also reports, on the same JSON line: `roofline` (live HIP-event timing of the dominant kernel), `secondary`
+(BASELINE configs 2-4, bounded step counts, each with the rate that bounds it) and `cpu_baseline` (the oracle on the
+host cores).
+
+N > 1: one rank per GPU.  Launched by `python -m torch.distributed.run ... bench.py --gpus N ...` the ranks come from
+the environment; launched as plain `python bench.py --gpus N` the script re-executes itself under
+torch.distributed.run with N ranks (and refuses to run if the box has fewer than N GPUs).  The headline `value` at
+N > 1 is N independent requests, one engine replica per GPU, no data-path collective ("scaling": "weak"; a batch-1
+request is a sequential chain of layers and does not shard for speed); the timed region is bracketed by barriers and
+the max over ranks is used.  The same line then carries `pp` (the target's layers sharded over the N ranks, RCCL
+send/recv of the [T, H] activation -- BASELINE config 5) and `tp` (every layer split over the N ranks, two
+all-reduces per layer), each ONE request over all N GPUs measured after the replicas.  A watchdog ends a phase that
+hangs and still prints the line.
 """
 from __future__ import annotations
 
@@ -30,6 +39,7 @@ import os
 
 os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")   # benchmarks run on seeded random weights of the exact shapes (no checkpoints offline)
 import sys
+import threading
 import time
 
 import torch
@@ -46,11 +56,36 @@ WORKLOADS = {
                   tree="5x6", desc="Llama-3.1-8B-Instruct target + Llama-3.2-1B draft, bf16, static Sequoia 5x6 (T=31), greedy"),
     "1b+1b": dict(target="meta-llama/Llama-3.2-1B-Instruct", draft="meta-llama/Llama-3.2-1B-Instruct", dtype="fp16",
                   tree="3x4", desc="Llama-3.2-1B target + Llama-3.2-1B draft, fp16, static Sequoia 3x4, greedy"),
+    # plumbing check of the multi-rank paths on small boxes / in tests: NOT a benchmark configuration
+    "tiny": dict(target="umb-test/tiny-target", draft="umb-test/tiny-draft", dtype="fp16", tree="3x4", vocab_hi=500,
+                 desc="tiny seeded Llama pair (tests only)"),
 }
 ACC_5x6 = [0.5, 0.2, 0.12, 0.08, 0.05, 0.03]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
+T70 = "hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4"
+D1B = "meta-llama/Llama-3.2-1B-Instruct"
+D8BAWQ = "hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4"
 
 
+def register_tiny():
+    """the `tiny` workload's two architectures (the golden fixtures' shapes), registered like hub ids"""
+    from umbrella_amd.models.auto_model import AutoModelLM
+    from umbrella_amd.models.config import KNOWN, LLAMA3_ROPE, LlamaCfg
+    from umbrella_amd.models.llama import Llama
+    tiny = {"umb-test/tiny-target": LlamaCfg(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                                             num_attention_heads=4, num_key_value_heads=2, head_dim=64, rope_scaling=LLAMA3_ROPE,
+                                             eos_token_id=[3, 5], name="tiny-target"),
+            "umb-test/tiny-draft": LlamaCfg(vocab_size=512, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                            num_attention_heads=2, num_key_value_heads=1, head_dim=64, rope_scaling=LLAMA3_ROPE,
+                                            tie_word_embeddings=True, eos_token_id=[3, 5], name="tiny-draft")}
+    for k, v in tiny.items():
+        KNOWN[k] = v
+        for table in (AutoModelLM._MODEL_MAPPING, AutoModelLM._OFFLOAD_MODEL_MAPPING, AutoModelLM._CUDAGRAPH_MODEL_MAPPING):
+            table[k] = Llama
+
+
+# ------------------------------------------------------------------ launch plumbing
 def dist_env():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,20 +93,82 @@ def dist_env():
     return rank, world, local
 
 
-def build_engine(wl, device, dtype, max_length, seed, pp=None):
+def share_gpu() -> bool:
+    """tests on a one-GPU box: every rank drives cuda:0 and the ranks talk over gloo (host staged)"""
+    return os.environ.get("UMB_BENCH_SHARE_GPU", "0") == "1"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not (args.dry_run or share_gpu()):
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s); refusing to report an "
+                             f"{args.gpus}-GPU number from fewer devices")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+class Watchdog:
+    """A phase that never returns (a rank died, a collective hangs) must not take the bench line with it: after the
+    deadline rank 0 prints the line with what it has and every rank leaves."""
+
+    def __init__(self, rank, emit):
+        self.rank, self.emit = rank, emit
+        self.deadline, self.phase = None, None
+        self.lock = threading.Lock()
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def arm(self, phase, seconds):
+        with self.lock:
+            self.phase, self.deadline = phase, time.time() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.time() > self.deadline
+                phase = self.phase
+            if late:
+                try:
+                    if self.rank == 0:
+                        self.emit(f"timeout in phase '{phase}'")
+                    else:
+                        time.sleep(3.0)         # rank 0 prints first: a worker that exits makes the launcher stop the others
+                finally:
+                    sys.stdout.flush()
+                    os._exit(0)                 # the line is out: a non-zero status would only hide it from the driver
+
+
+# ------------------------------------------------------------------ engines
+def growmap_for(tree):
     from umbrella_amd.sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
-    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
-    if wl["tree"] == "3x4":
-        gm, acc = generate_sequoia_tree(3, 4), DEFAULT_ACC
-    elif wl["tree"] == "mi355x-T16d3":
+    if tree == "3x4":
+        return generate_sequoia_tree(3, 4), DEFAULT_ACC
+    if tree == "mi355x-T16d3":
         # growmap re-tuned for the measured MI355X cost ratios (scripts/tune_growmap.py, profiles/r02_growmap_tuning_*.json):
         # the 15 most probable nodes of depth <= 3 under the same acceptance vector -- one draft forward fewer, a full
         # 16-row token tile in the verify
-        import json as _json
         with open(os.path.join(ROOT, "umbrella_amd", "trees", "mi355x_70b_awq_1b-T16d3.json")) as f:
-            gm, acc = _json.load(f), DEFAULT_ACC
-    else:
-        gm, acc = generate_sequoia_tree(5, 6, ACC_5x6), ACC_5x6
+            return json.load(f), DEFAULT_ACC
+    return generate_sequoia_tree(5, 6, ACC_5x6), ACC_5x6
+
+
+def build_engine(wl, device, dtype, max_length, seed):
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    gm, acc = growmap_for(wl["tree"])
     eng = StaticSpeculationEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=gm,
                                   max_length=max_length, exit_layer=16, seed=seed)
     eng.initialize()
@@ -97,7 +194,6 @@ def kernel_roofline(eng, reps=40):
     dt = _lib.dtype_code(m.dtype)
     res = {}
     L = m.num_layers
-    lib = _lib.load()
     for key in ("qkv", "o", "gu", "down"):
         lin0 = m.layers[0][key]
         N, K = lin0.N, lin0.K
@@ -154,6 +250,38 @@ def kernel_roofline(eng, reps=40):
     return res
 
 
+def roofline_block(eng):
+    m = eng.target_model
+    kr = kernel_roofline(eng)
+    dom = max(kr.values(), key=lambda r: r["bytes"])
+    tot_b, tot_us = sum(r["bytes"] for r in kr.values()), sum(r["us"] for r in kr.values())
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
+    # the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md); it is
+    # only reported while the kernel source it was taken from is unchanged (sha256 of csrc/gemm.hip recorded there)
+    traffic, tsrc = None, None
+    import hashlib
+    with open(os.path.join(ROOT, "umbrella_amd", "csrc", "gemm.hip"), "rb") as f:
+        src_hash = hashlib.sha256(f.read()).hexdigest()[:16]
+    for pmc_name in ("r03_pmc_gemm70b_traffic.json", "r02_pmc_gemm70b_traffic.json"):
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
+            with open(pmc) as f:
+                rec = json.load(f)
+            if rec.get("gemm_hip_sha256_16") == src_hash:      # a figure taken on other kernel source is not reported
+                traffic = rec["gate_up_traffic_bytes"]
+                tsrc = f"static: profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this gemm.hip)"
+                break
+    return {"bound": "hbm", "kernel": f"{dom['family']} {'int4' if m.config.awq else 'dense'} gate_up "
+                                      f"N={dom['N']} K={dom['K']} T={eng.tree_size}",
+            "achieved": round(dom["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+            "avg_launch_us": round(dom["us"], 2), "bytes_per_launch": dom["bytes"],
+            "layer_gemms": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                if kk not in ("N", "K", "bytes")} for k, v in kr.items()},
+            "layer_gemms_GBs": round(tot_b / tot_us / 1e3, 1)}
+
+
+# ------------------------------------------------------------------ CPU baseline (the oracle, rank 0, N = 1 only)
 def _oracle_state(cfg, layers, alias):
     """fp32 random state dict for the oracle; with alias=True the `layers` decoder layers share one set of tensors
     (full-depth arithmetic and memory traffic -- a 70B layer is 3.4 GB in fp32, far beyond any cache -- at one
@@ -179,7 +307,7 @@ def _oracle_state(cfg, layers, alias):
     return sd
 
 
-def cpu_baseline(wl, gm, accept_len, threads, budget_s=30.0):
+def cpu_baseline(wl, gm, accept_len, threads):
     """Oracle ("port": torch CPU fp32, AWQ dequantised at load as a CPU port would) MEASURED end to end on the host
     cores on a bounded sample of the same workload: one whole static-tree iteration -- every draft forward of the
     iteration on the full 16-layer draft and the T-row verify through ALL target layers + lm_head -- at a 128-token
@@ -199,7 +327,7 @@ def cpu_baseline(wl, gm, accept_len, threads, budget_s=30.0):
         return OracleLlama(cfg, sd, inv, sc, max_length=256, dtype=torch.float32)
 
     def forward(m, rows):
-        ids = torch.randint(3, 1000, (1, rows))
+        ids = torch.randint(3, 500, (1, rows))
         pos = torch.arange(P, P + rows)[None]
         mk = torch.ones(rows, 256, dtype=torch.bool)
         m.kv_cache.kv_offset = P
@@ -225,52 +353,156 @@ def cpu_baseline(wl, gm, accept_len, threads, budget_s=30.0):
                       f"and traffic; tokens/s at the GPU run's accept_len {accept_len:.2f}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", default="70b-awq+1b", choices=sorted(WORKLOADS))
-    ap.add_argument("--prompt-len", type=int, default=128)
-    ap.add_argument("--max-length", type=int, default=2048)
-    ap.add_argument("--tree", default=None, choices=[None, "3x4", "5x6", "mi355x-T16d3"],
-                    help="growmap override (default: the workload's reference tree); mi355x-T16d3 = the re-tuned tree, a "
-                         "second line next to the headline, never the headline itself")
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "pp", "tp"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--seed", type=int, default=0)
-    args = ap.parse_args()
+# ------------------------------------------------------------------ secondary configurations (BASELINE configs 2-4), N = 1
+def _timed_steps(eng, prompt, warm, steps):
+    assert eng._prefill(prompt)
+    for _ in range(warm):
+        eng.step()
+    torch.cuda.synchronize()
+    start, t0 = eng.num_nodes, time.time()
+    for _ in range(steps):
+        eng.step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    return dt / steps * 1e3, (eng.num_nodes - start) / steps
 
-    rank, world, local = dist_env()
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    device = f"cuda:{local}"
-    torch.cuda.set_device(local)
-    wl = dict(WORKLOADS[args.workload])
-    if args.tree:
-        wl["tree"] = args.tree
-        wl["desc"] = wl["desc"] + f" [growmap override: {args.tree}]"
-    dtype = torch.float16 if wl["dtype"] == "fp16" else torch.bfloat16
 
-    if args.parallel == "pp" and world > 1:
-        from umbrella_amd.parallel import run_pp_bench
-        return run_pp_bench(args, wl, dtype, device, rank, world)
-    if args.parallel == "tp":
-        if world == 1:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(device))
-        from umbrella_amd.tensor_parallel import run_tp_bench
-        return run_tp_bench(args, wl, dtype, device, rank, world)
+def _event_ms(fn, reps=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
-    import __graft_entry__ as ge
-    ge.build()
+
+def secondary_configs(device, seed=0):
+    """BASELINE configs 2-4 on this GPU with bounded step counts (raw random-weight draft: accept ~1, so only
+    `ms_per_step` and the rates are meaningful), each with the figure that bounds it: C2 HBM GB/s, C3-resident and C4
+    dense MFMA TFLOP/s of the verify forward, C3-offload host-link GB/s at num_cache_layers 0 and 40."""
+    from umbrella_amd.models import AutoModelLM
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree
+    from umbrella_amd.speculation.auto_engine import AutoEngine
+    out = {}
+    prompt = torch.randint(3, 128000, (1, 128), generator=torch.Generator().manual_seed(0))
+
+    def guarded(name, fn):
+        t0 = time.time()
+        try:
+            out[name] = fn()
+        except Exception as e:                                  # a secondary line never takes the headline with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.time() - t0, 1)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def c2():
+        eng = AutoEngine.from_config(device, engine="static", model="meta-llama/Llama-3.1-8B-Instruct", draft_model=D1B,
+                                     dtype=torch.bfloat16, growmap=generate_sequoia_tree(5, 6, ACC_5x6), max_length=2048,
+                                     exit_layer=16, seed=seed)
+        eng.initialize()
+        ms, acc = _timed_steps(eng, prompt, 3, 24)
+        m, d = eng.target_model, eng.draft_model
+        n_fwd = len(eng.levels) - 1 if eng.lookback else len(eng.levels)
+        b = n_fwd * d.weight_bytes() + m.weight_bytes()
+        return {"config": "C2: Llama-3.1-8B bf16 target + 1B draft, static Sequoia 5x6 (T=31), on-device", "ms_per_step": round(ms, 3),
+                "accept_len_raw_draft": round(acc, 2), "iter_bytes_GB": round(b / 1e9, 2), "bound": "hbm",
+                "achieved_GBs": round(b / ms / 1e6, 1), "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    shared = {}
+
+    def target70(max_length=4096):
+        if "t" not in shared:
+            t = AutoModelLM.from_pretrained(T70, max_length=max_length, device=device, dtype=torch.float16, seed=seed)
+            t.alloc()
+            shared["t"] = t
+        return shared["t"]
+
+    def verify_rate(eng):
+        """dense MFMA rate of the verify forward alone (events on the launch stream), 2 T (layer + head parameters) flops"""
+        t = eng.target_model
+        ms = _event_ms(eng._verify_forward)
+        params = sum(ln.N * ln.K for ln in t.layers[0].values()) * t.num_layers + t.lm_head.N * t.lm_head.K
+        tf = 2.0 * eng.tree_size * params / (ms * 1e-3) / 1e12
+        return {"verify_ms": round(ms, 2), "verify_TFLOPs": round(tf, 1), "bound": "mfma",
+                "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
+
+    def c3_resident():
+        t = target70()
+        d = AutoModelLM.from_pretrained(D1B, max_length=t.max_length, device=device, dtype=torch.float16, seed=seed)
+        d.alloc()
+        eng = AutoEngine.from_config(device, engine="dynamic", model=T70, draft_model=D1B, dtype=torch.float16, width=16,
+                                     num_beams=24, depth=16, max_length=t.max_length, offload=False, target_model_obj=t,
+                                     draft_model_obj=d, seed=seed)
+        eng.initialize()
+        ms, acc = _timed_steps(eng, prompt, 2, 8)
+        r = {"config": "C3 with the target resident: 70B-AWQ + 1B draft, dynamic w16/b24/d16 (T=257)", "ms_per_step": round(ms, 2),
+             "accept_len_raw_draft": round(acc, 2)}
+        r.update(verify_rate(eng))
+        eng.reset()
+        return r
+
+    def c4():
+        t = target70()
+        d = AutoModelLM.from_pretrained(D8BAWQ, max_length=t.max_length, device=device, dtype=torch.float16, seed=seed)
+        d.alloc()
+        eng = AutoEngine.from_config(device, engine="dynamic", model=T70, draft_model=D8BAWQ, dtype=torch.float16, width=32,
+                                     num_beams=32, depth=24, max_length=t.max_length, offload=False, temperature=0.6, topp=0.9,
+                                     topk=32, repetition_penalty=1.05, target_model_obj=t, draft_model_obj=d, seed=seed)
+        eng.initialize()
+        ms, acc = _timed_steps(eng, prompt, 1, 4)
+        r = {"config": "C4: 70B-AWQ + 8B-AWQ draft, dynamic w32/b32/d24 (T=769), stochastic (T 0.6, top-p 0.9, top-k 32, "
+                       "penalty 1.05)", "ms_per_step": round(ms, 2), "accept_len_raw_draft": round(acc, 2)}
+        r.update(verify_rate(eng))
+        eng.reset()
+        return r
+
+    def prefill():
+        t = target70()
+        ids = torch.randint(3, 128000, (2048,), generator=torch.Generator().manual_seed(1)).int().to(device)
+        t.reserve(t.PREFILL_CHUNK, logit_rows=64)
+        t.clear(); t.prefill_tokens(ids, 0); torch.cuda.synchronize()
+        t.clear(); t0 = time.time(); t.prefill_tokens(ids, 0); torch.cuda.synchronize()
+        dt = time.time() - t0
+        t.clear()
+        params = sum(ln.N * ln.K for ln in t.layers[0].values()) * t.num_layers
+        tf = 2.0 * 2048 * params / dt / 1e12
+        return {"config": "70B-AWQ prompt of 2048 tokens, 1024-token chunks", "tok_s": round(2048 / dt, 0), "ms": round(dt * 1e3, 1),
+                "TFLOPs": round(tf, 1), "bound": "mfma", "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
+
+    def c3_offload(ncl):
+        def run():
+            eng = AutoEngine.from_config(device, engine="dynamic", model=T70, draft_model=D1B, dtype=torch.float16, width=16,
+                                         num_beams=24, depth=16, max_length=4096, offload=True, num_cache_layers=ncl, seed=seed)
+            eng.initialize()
+            ms, acc = _timed_steps(eng, prompt, 1, 3)
+            m = eng.target_model
+            streamed = sum(1 for h in m.host_slabs if h is not None) * m.slab_bytes
+            return {"config": f"C3: 70B-AWQ layers streamed from pinned host DRAM, num_cache_layers {ncl}, 1B draft, dynamic "
+                              "w16/b24/d16 (T=257)", "ms_per_step": round(ms, 1), "accept_len_raw_draft": round(acc, 2),
+                    "streamed_GB_per_verify": round(streamed / 1e9, 2), "bound": "host link (PCIe Gen5 x16, 63 GB/s spec)",
+                    "achieved_GBs": round(streamed / ms / 1e6, 1), "frac": round(streamed / ms / 1e6 / 63.0, 4)}
+        return run
+
+    guarded("c2", c2)
+    guarded("c3_resident", c3_resident)
+    guarded("c4", c4)
+    guarded("prefill_70b", prefill)
+    shared.clear()
+    torch.cuda.empty_cache()
+    guarded("c3_offload_ncl0", c3_offload(0))
+    guarded("c3_offload_ncl40", c3_offload(40))
+    return out
+
+
+# ------------------------------------------------------------------ the headline loop (per rank)
+def headline(args, wl, dtype, device, rank, world, dist, agg_device):
     eng, gm, acc = build_engine(wl, device, dtype, args.max_length, args.seed + rank)
     g = torch.Generator().manual_seed(1234 + rank)
-    prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)           # examples/bench.py:31
+    prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)           # examples/bench.py:31
 
     # ---- untimed: the target's own greedy continuation (ground truth for the acceptance knob)
     need = (args.warmup + args.steps) * len(gm["roots"]) + 16
@@ -325,84 +557,214 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.time() - t0
+    dt, tokens = aggregate(dt, tokens, world, dist, agg_device)
+    info = dict(start=start, raw_tps=raw_tps, raw_accept=raw_accept, passes=passes)
+    return eng, gm, acc, dt, tokens, info
+
+
+def aggregate(dt, tokens, world, dist, agg_device):
+    """max over ranks of the timed region, sum over ranks of the units processed"""
     if world > 1:
-        tt = torch.tensor([dt, float(tokens)], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt, float(tokens)], dtype=torch.float64, device=agg_device)
         mx = tt.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         dt, tokens = float(mx[0]), float(tt[1])
-    accept_len = tokens / (args.steps * world)
-    value = tokens / dt
+    return dt, tokens
 
-    out = None
-    if rank == 0:
-        m, d = eng.target_model, eng.draft_model
-        levels = [len(x) for x in gm["roots"]]
-        n_mid = start + tokens / world / 2
-        kv_t = m.num_layers * 2 * m.config.num_key_value_heads * m.config.head_dim * 2
-        kv_d = d.num_layers * 2 * d.config.num_key_value_heads * d.config.head_dim * 2
-        # draft forwards actually executed per iteration: one per expanded level (the reference's extra KV-fill
-        # forward over the deepest level is folded into the next root forward, engine_common._draft_root), each
-        # with its lm_head; without the look-back the reference count (len(levels), last one without lm_head)
-        if getattr(eng, "lookback", False):
-            n_fwd = len(levels) - 1
-            draft_fwd = d.weight_bytes()
+
+def headline_line(args, wl, eng, gm, acc, dt, tokens, info, world):
+    m, d = eng.target_model, eng.draft_model
+    levels = [len(x) for x in gm["roots"]]
+    accept_len = tokens / (args.steps * world)
+    n_mid = info["start"] + tokens / world / 2
+    kv_t = m.num_layers * 2 * m.config.num_key_value_heads * m.config.head_dim * 2
+    kv_d = d.num_layers * 2 * d.config.num_key_value_heads * d.config.head_dim * 2
+    # draft forwards actually executed per iteration: one per expanded level (the reference's extra KV-fill
+    # forward over the deepest level is folded into the next root forward, engine_common._draft_root), each
+    # with its lm_head; without the look-back the reference count (len(levels), last one without lm_head)
+    if getattr(eng, "lookback", False):
+        n_fwd = len(levels) - 1
+        draft_fwd = d.weight_bytes()
+    else:
+        n_fwd = len(levels)
+        draft_fwd = d.weight_bytes() - (d.lm_head.N * d.lm_head.K * 2) / len(levels)
+    bytes_iter = n_fwd * draft_fwd + m.weight_bytes() + n_mid * (kv_t + n_fwd * kv_d)
+    iter_ms = dt / args.steps * 1e3
+    return {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(iter_ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"],
+            "data": "synthetic: random-init weights of the exact shapes, random prompt ids; acceptance set by the "
+                    "controllable-acceptance draft (acc vector below), all draft/verify kernels execute",
+            "config": {"workload": wl["desc"], "engine": "static", "tree": wl["tree"], "tree_size": eng.tree_size,
+                       "prompt_len": args.prompt_len, "max_length": args.max_length, "acc": acc,
+                       "parallelism": "1 engine per GPU (replicas: independent requests, no data-path collective)"
+                       if world > 1 else "single GPU"},
+            "accept_len": round(accept_len, 3), "value_raw_draft": round(info["raw_tps"], 2),
+            "accept_len_raw_draft": round(info["raw_accept"], 3), "oracle_draft_divergence": getattr(eng, "diverged", 0),
+            "oracle_draft_passes": info["passes"], "schedule": getattr(m, "sched", "split"),
+            "draft_forwards_per_iter": n_fwd, "iter_bytes_GB": round(bytes_iter / 1e9, 3),
+            "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def dry_run(args, rank, world, dist):
+    """Launch-plumbing check without a GPU (tests): the ranks come up over gloo, the timed region is a sleep, the
+    aggregation (barriers, max over ranks, sum of units) and the one-line report are the real code."""
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    tokens = 3 * args.steps
+    if world > 1:
+        dist.barrier()
+    dt, tokens = aggregate(time.time() - t0, tokens, world, dist, "cpu")
+    return {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "dry_run": True,
+            "data": "DRY RUN: no GPU work, launch plumbing only", "config": {"workload": "dry run"},
+            "accept_len": round(tokens / (args.steps * world), 3), "pp": {"skipped": "dry run"}, "tp": {"skipped": "dry run"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="70b-awq+1b", choices=sorted(WORKLOADS))
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--max-length", type=int, default=2048)
+    ap.add_argument("--tree", default=None, choices=[None, "3x4", "5x6", "mi355x-T16d3"],
+                    help="growmap override (default: the workload's reference tree); mi355x-T16d3 = the re-tuned tree, a "
+                         "second line next to the headline, never the headline itself")
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "pp", "tp"],
+                    help="replicas (default): the headline; at N > 1 followed by the pp and tp measurements on the same "
+                         "line.  pp / tp: that engine alone (its own line)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2-4 (N = 1)")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the pp / tp measurements (N > 1)")
+    ap.add_argument("--sharded-steps", type=int, default=16, help="timed iterations of the pp / tp measurements")
+    ap.add_argument("--phase-timeout", type=float, default=240.0, help="watchdog per pp / tp phase, seconds")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    self_launch(args)                                   # N > 1 outside torch.distributed.run: re-exec with N ranks
+
+    rank, world, local = dist_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         "(python -m torch.distributed.run --nproc-per-node N ..., or plain `python bench.py --gpus N`)")
+    dist = None
+    gloo = args.dry_run or share_gpu()
+    if not args.dry_run:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (MI355X); use --dry-run for the launch plumbing alone")
+        dev_index = 0 if share_gpu() else local
+        if torch.cuda.device_count() <= dev_index:
+            raise SystemExit(f"rank {rank}: no GPU {dev_index} on this box ({torch.cuda.device_count()} visible): "
+                             f"--gpus {args.gpus} needs {args.gpus} devices")
+        torch.cuda.set_device(dev_index)
+        device = f"cuda:{dev_index}"
+    if world > 1 or args.parallel != "replicas":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            n_fwd = len(levels)
-            draft_fwd = d.weight_bytes() - (d.lm_head.N * d.lm_head.K * 2) / len(levels)
-        bytes_iter = n_fwd * draft_fwd + m.weight_bytes() + n_mid * (kv_t + n_fwd * kv_d)
-        iter_ms = dt / args.steps * 1e3
-        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(value, 2), "unit": "tokens/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(iter_ms, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"],
-               "data": "synthetic: random-init weights of the exact shapes, random prompt ids; acceptance set by the "
-                       "controllable-acceptance draft (acc vector below), all draft/verify kernels execute",
-               "config": {"workload": wl["desc"], "engine": "static", "tree": wl["tree"], "tree_size": eng.tree_size,
-                          "prompt_len": args.prompt_len, "max_length": args.max_length, "acc": acc,
-                          "parallelism": "1 engine per GPU (replicas)" if world > 1 else "single GPU"},
-               "accept_len": round(accept_len, 3), "value_raw_draft": round(raw_tps, 2),
-               "accept_len_raw_draft": round(raw_accept, 3), "oracle_draft_divergence": getattr(eng, "diverged", 0), "oracle_draft_passes": passes,
-               "schedule": getattr(m, "sched", "split"),
-               "draft_forwards_per_iter": n_fwd, "iter_bytes_GB": round(bytes_iter / 1e9, 3),
-               "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus} asked for")
+    if args.dry_run:
+        out = dry_run(args, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
+
+    if args.workload == "tiny":
+        register_tiny()
+    wl = dict(WORKLOADS[args.workload])
+    if args.tree:
+        wl["tree"] = args.tree
+        wl["desc"] = wl["desc"] + f" [growmap override: {args.tree}]"
+    dtype = torch.float16 if wl["dtype"] == "fp16" else torch.bfloat16
+    agg_device = "cpu" if gloo else device
+
+    if args.parallel == "pp":
+        from umbrella_amd.parallel import run_pp_bench
+        return run_pp_bench(args, wl, dtype, device, rank, world)
+    if args.parallel == "tp":
+        from umbrella_amd.tensor_parallel import run_tp_bench
+        return run_tp_bench(args, wl, dtype, device, rank, world)
+
+    import __graft_entry__ as ge
+    ge.build()
+    eng, gm, acc, dt, tokens, info = headline(args, wl, dtype, device, rank, world, dist, agg_device)
+    out = headline_line(args, wl, eng, gm, acc, dt, tokens, info, world)
+    accept_len = out["accept_len"]
+
+    if world == 1:
         if not args.no_roofline:
-            kr = kernel_roofline(eng)
-            dom = max(kr.values(), key=lambda r: r["bytes"])
-            tot_b, tot_us = sum(r["bytes"] for r in kr.values()), sum(r["us"] for r in kr.values())
-            # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
-            # the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/README.md); it is
-            # only reported while the kernel source it was taken from is unchanged (sha256 of csrc/gemm.hip recorded there)
-            traffic, tsrc = None, None
-            import hashlib
-            with open(os.path.join(ROOT, "umbrella_amd", "csrc", "gemm.hip"), "rb") as f:
-                src_hash = hashlib.sha256(f.read()).hexdigest()[:16]
-            for pmc_name in ("r02_pmc_gemm70b_traffic.json",):
-                pmc = os.path.join(ROOT, "profiles", pmc_name)
-                if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
-                    with open(pmc) as f:
-                        rec = json.load(f)
-                    if rec.get("gemm_hip_sha256_16") == src_hash:      # a figure taken on other kernel source is not reported
-                        traffic = rec["gate_up_traffic_bytes"]
-                        tsrc = f"static: profiles/{pmc_name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this gemm.hip)"
-                        break
-            out["roofline"] = {"bound": "hbm", "kernel": f"{dom['family']} {'int4' if m.config.awq else 'dense'} gate_up "
-                                                       f"N={dom['N']} K={dom['K']} T={eng.tree_size}",
-                               "achieved": round(dom["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                               "avg_launch_us": round(dom["us"], 2), "bytes_per_launch": dom["bytes"],
-                               "layer_gemms": {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()
-                                                   if kk not in ("N", "K", "bytes")} for k, v in kr.items()},
-                               "layer_gemms_GBs": round(tot_b / tot_us / 1e3, 1)}
-        if not args.no_cpu_baseline and world == 1:          # the CPU leg runs on rank 0 at N = 1 only
+            out["roofline"] = roofline_block(eng)
+        del eng
+        torch.cuda.empty_cache()
+        if not args.no_secondary and args.workload == "70b-awq+1b":
+            out["secondary"] = secondary_configs(device, args.seed)
+        if not args.no_cpu_baseline and args.workload != "tiny":          # the CPU leg runs on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, gm, accept_len, torch.get_num_threads())
             except Exception as e:                                        # never lose the GPU line to the baseline leg
                 out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+
+    # ---- N > 1: the sharded engines, ONE request over all N GPUs each, on the same line
+    del eng
+    torch.cuda.empty_cache()
+    printed = threading.Event()
+
+    def emit(err=None):
+        if printed.is_set():
+            return
+        printed.set()
+        if err:
+            out["sharded_error"] = err
+            out.setdefault("pp", {"error": err})
+            out.setdefault("tp", {"error": err})
+        print(json.dumps(out), flush=True)
+
+    if args.no_sharded:
+        out["pp"] = out["tp"] = {"skipped": "--no-sharded"}
+    else:
+        wd = Watchdog(rank, emit)
+        sargs = argparse.Namespace(**vars(args))
+        sargs.steps, sargs.warmup = args.sharded_steps, max(2, min(args.warmup, 4))
+        for name, mod, fn in (("pp", "umbrella_amd.parallel", "pp_measure"), ("tp", "umbrella_amd.tensor_parallel", "tp_measure")):
+            wd.arm(name, args.phase_timeout)
+            try:
+                import importlib
+                r = getattr(importlib.import_module(mod), fn)(sargs, wl, dtype, device, rank, world)
+                if rank == 0:
+                    out[name] = r
+            except Exception as e:      # an exception on one rank may leave the others in a collective: the watchdog ends them
+                import traceback
+                traceback.print_exc()
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.empty_cache()
+        wd.disarm()
+    if rank == 0:
+        emit()
+    dist.barrier()
+    dist.destroy_process_group()
     return out
 
 

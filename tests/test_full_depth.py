@@ -1,0 +1,128 @@
+"""Full-depth engines at the real BASELINE shapes (GPU): config 2 (Llama-3.1-8B bf16 target + Llama-3.2-1B draft, static
+Sequoia 5x6) and the headline pairing (Llama-3.1-70B-Instruct-AWQ-INT4 target + 1B draft, static 3x4, fp16), every
+layer of every model, seeded random-init weights of the exact shapes (no checkpoints offline).
+
+No CPU oracle finishes an 80-layer 70B forward in test time, so parity is stated through the size-independent properties
+the domain offers:
+  (1) hipGraph replay == eager launches, token for token;
+  (2) greedy speculative decoding == greedy autoregressive decoding with the target alone (T = 1 forwards): every
+      emitted token is the arg-max of the autoregressive row that precedes it (teacher forced along the emitted sequence);
+      the only accepted exception is a row whose top-2 logit margin lies inside the 16-bit noise band (the GEMMs are
+      batch invariant, tree attention sums keys in a different order than a 1-row forward);
+  (3) the same with the tree really exercised: the controllable-acceptance draft (bench.py's knob) places the target's
+      own continuation in the tree, accept length > 2, tokens still == AR.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NEW = 40
+TOL = {torch.bfloat16: 0.35, torch.float16: 0.06}
+
+
+def _ar(target, prompt, n, dev):
+    """greedy decode with the target alone (T = 1 forwards)"""
+    target.clear()
+    row = target.prefill_tokens(torch.tensor(prompt, dtype=torch.int32, device=dev), 0)
+    toks = []
+    for i in range(n):
+        toks.append(int(row.argmax()))
+        if i + 1 < n:
+            row = target.prefill_tokens(torch.tensor([toks[-1]], dtype=torch.int32, device=dev), len(prompt) + i)
+    target.clear()
+    return toks
+
+
+def _check_against_ar(target, prompt, toks, tol, dev, what):
+    """Teacher-forced autoregressive check: the target alone walks prompt + toks one token per forward; token i must be
+    the arg-max of the row that precedes it.  Where that row's top-2 margin is inside the 16-bit noise band (2 tol) the
+    speculative decode may have taken the runner-up (tree attention sums keys in another order) -- it must then be
+    within 2 tol of the maximum.  Returns the number of exact arg-max agreements."""
+    target.clear()
+    row = target.prefill_tokens(torch.tensor(prompt, dtype=torch.int32, device=dev), 0)
+    exact = 0
+    for i, tok in enumerate(toks):
+        top2 = row.topk(2).values
+        best, margin, gap = int(row.argmax()), float(top2[0] - top2[1]), float(top2[0] - row[tok])
+        if tok == best:
+            exact += 1
+        else:
+            assert margin < 2 * tol and gap < 2 * tol, \
+                f"{what}: token {i} = {tok} is not the autoregressive choice {best} (margin {margin:.4f}, gap {gap:.4f})"
+        if i + 1 < len(toks):
+            row = target.prefill_tokens(torch.tensor([tok], dtype=torch.int32, device=dev), len(prompt) + i)
+    target.clear()
+    return exact
+
+
+def _run_pair(target_name, draft_name, dtype, tree, acc, dev):
+    from umbrella_amd.models import AutoModelLM
+    from umbrella_amd.sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    L = 512
+    target = AutoModelLM.from_pretrained(target_name, max_length=L, device=str(dev), dtype=dtype)
+    target.alloc()
+    draft = AutoModelLM.from_pretrained(draft_name, max_length=L, device=str(dev), dtype=dtype, cuda_graph=True)
+    draft.alloc(exit_layer=16)
+    assert target.num_layers == target.config.num_hidden_layers and draft.num_layers == draft.config.num_hidden_layers
+    gm = generate_sequoia_tree(*tree) if acc is None else generate_sequoia_tree(*tree, acc)
+    acc = DEFAULT_ACC if acc is None else acc
+    prompt = torch.randint(3, 128000, (96,), generator=torch.Generator().manual_seed(1)).tolist()
+
+    def engine(graph):
+        e = StaticSpeculationEngine(draft_name, target_name, dtype=dtype, device=str(dev), growmap=gm, max_length=L,
+                                    draft_model_obj=draft, target_model_obj=target, tokenizer=IdTokenizer(), hip_graph=graph)
+        e.initialize()
+        return e
+
+    eg, ee = engine(True), engine(False)
+    tol = TOL[dtype]
+    ar = _ar(target, prompt, NEW + 16, dev)                             # after initialize(): the workspaces are final
+    out_g = eg.generate(input_ids=prompt, max_new_tokens=NEW)
+    out_e = ee.generate(input_ids=prompt, max_new_tokens=NEW)
+    tg, te = out_g["generated_tokens"], out_e["generated_tokens"]
+    assert tg == te, "hipGraph replay and eager launches disagree"
+    assert len(tg) >= NEW
+    exact = _check_against_ar(target, prompt, tg, tol, dev, "raw draft")
+    # (3) the tree exercised: the target's own continuation steered into the tree
+    assert eg._prefill(torch.tensor([prompt]))
+    start = eg.num_nodes
+    eg.set_oracle_draft(ar, start, acc, seed=0)
+    steps = 0
+    while eg.num_nodes - start < NEW and eg.validate_status():
+        eg.step()
+        steps += 1
+    tk = eg.tokens[start:eg.num_nodes + 1].tolist()
+    accept = (eg.num_nodes - start) / max(steps, 1)
+    eg.reset()
+    exactk = _check_against_ar(target, prompt, tk, tol, dev, "steered draft")
+    same = next((i for i in range(min(len(tg), len(ar))) if tg[i] != ar[i]), min(len(tg), len(ar)))
+    return dict(n=len(tg), exact=exact, nk=len(tk), exactk=exactk, accept=accept, same_as_free_ar=same,
+                raw_accept=out_g["avg_accept_tokens"])
+
+
+def _assert_pair(r):
+    # at most a handful of 16-bit near-ties in 40+ tokens (each one margin-checked above), the rest exact
+    assert r["n"] >= NEW and r["exact"] >= r["n"] - 3, r
+    assert r["nk"] >= NEW and r["exactk"] >= r["nk"] - 3, r
+    assert r["accept"] > 2.0, r
+    print(r)
+
+
+def test_c2_8b_bf16_with_1b_draft_5x6():
+    """BASELINE config 2: Llama-3.1-8B-Instruct target + Llama-3.2-1B draft, bf16, static Sequoia 5x6 (T = 31), all 32 + 16
+    layers.  8B target on the split schedule, 1B draft on the low-latency one (UMB_SCHED=auto)."""
+    dev = torch.device("cuda:0")
+    r = _run_pair("meta-llama/Llama-3.1-8B-Instruct", "meta-llama/Llama-3.2-1B-Instruct", torch.bfloat16, (5, 6),
+                  [0.5, 0.2, 0.12, 0.08, 0.05, 0.03], dev)
+    _assert_pair(r)
+
+
+def test_70b_awq_with_1b_draft_3x4():
+    """The headline pairing at full depth: 80 AWQ int4 layers + 16 draft layers, static 3x4 (T = 13), fp16."""
+    dev = torch.device("cuda:0")
+    r = _run_pair("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", "meta-llama/Llama-3.2-1B-Instruct",
+                  torch.float16, (3, 4), None, dev)
+    _assert_pair(r)

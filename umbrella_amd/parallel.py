@@ -333,9 +333,10 @@ def shutdown_pipeline(eng):
     eng._comm.plan(OP_STOP)
 
 
-def run_pp_bench(args, wl, dtype, device, rank, world):
-    """bench.py --parallel pp: one request, target layers sharded over the ranks (static 3x4, greedy)."""
-    import json
+def pp_measure(args, wl, dtype, device, rank, world):
+    """One request, the target's layers sharded over the ranks of the default process group (static 3x4, greedy; BASELINE
+    config 5): rank 0 drives and returns the result dict, the other ranks serve stage forwards inside this call and
+    return None.  Collective: every rank of the group must call it.  Nothing is printed, the group stays up."""
     import time
 
     import __graft_entry__ as ge
@@ -344,11 +345,9 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
     eng = build_pipelined_engine(device, dtype=dtype, seed=args.seed, model=wl["target"], draft_model=wl["draft"],
                                  growmap=generate_sequoia_tree(3, 4), max_length=args.max_length, exit_layer=16)
     if eng is None:
-        dist.barrier()
-        dist.destroy_process_group()
         return None
     g = torch.Generator().manual_seed(1234)
-    prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)
+    prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)
     assert eng._prefill(prompt)
     for _ in range(args.warmup):
         eng.step()
@@ -360,14 +359,29 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
     torch.cuda.synchronize()
     dt = time.time() - t0
     tokens = eng.num_nodes - start
+    layers = [hi - lo for lo, hi in split_layers(eng._stage_model.config.num_hidden_layers, world)]
     shutdown_pipeline(eng)
-    out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
-           "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
-           "config": {"workload": wl["desc"], "parallelism": f"pp{world}: target layers sharded, RCCL send/recv of [T,H]",
-                      "tree": "3x4", "prompt_len": args.prompt_len}, "accept_len": round(tokens / args.steps, 3)}
-    print(json.dumps(out), flush=True)
+    hop_bytes = eng.tree_size * eng._stage_model.config.hidden_size * 2
+    return {"ms_per_step": round(dt / args.steps * 1e3, 4), "tokens_per_s_raw_draft": round(tokens / dt, 2),
+            "accept_len_raw_draft": round(tokens / args.steps, 3), "n_ranks_rccl": world, "backend": dist.get_backend(),
+            "layers_per_rank": layers, "hops_per_verify": world - 1, "hop_bytes": hop_bytes,
+            "parallelism": f"pp{world}: target layers sharded, send/recv of the [T, H] activation per hop, one commit "
+                           "broadcast per iteration; draft + engine state on rank 0", "tree": "3x4", "scaling": "strong"}
+
+
+def run_pp_bench(args, wl, dtype, device, rank, world):
+    """bench.py --parallel pp: the layer-sharded engine alone, one JSON line from rank 0."""
+    import json
+    r = pp_measure(args, wl, dtype, device, rank, world)
+    out = None
+    if r is not None:
+        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s_raw_draft"], "unit": "tokens/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
+               "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
+               "config": {"workload": wl["desc"], "parallelism": r["parallelism"], "tree": "3x4", "prompt_len": args.prompt_len},
+               "accept_len": r["accept_len_raw_draft"], "pp": r}
+        print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return out

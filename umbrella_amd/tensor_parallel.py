@@ -387,10 +387,9 @@ class TensorParallelStaticEngine(_Static):
         self.sampled.copy_(self.target_model.sampled_ids[:self.tree_size])
 
 
-def run_tp_bench(args, wl, dtype, device, rank, world):
-    """bench.py --parallel tp: ONE request, every layer of the target split over the ranks (static tree, greedy).
-    SPMD -- all ranks run this function; rank 0 prints the JSON line.  Unmeasured on this project's single-GPU boxes."""
-    import json
+def tp_measure(args, wl, dtype, device, rank, world):
+    """ONE request, every layer of the target split over the ranks of the default process group (static 3x4, greedy).
+    SPMD -- every rank runs this; all return the result dict.  Nothing is printed, the group stays up."""
     import time
 
     import torch.distributed as dist
@@ -410,7 +409,7 @@ def run_tp_bench(args, wl, dtype, device, rank, world):
                                      max_length=args.max_length, draft_model_obj=draft, tp_target=tp, seed=args.seed)
     eng.initialize()
     g = torch.Generator().manual_seed(1234)
-    prompt = torch.randint(3, 128000, (1, args.prompt_len), generator=g)
+    prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)
     assert eng._prefill(prompt)
     for _ in range(args.warmup):
         eng.step()
@@ -426,15 +425,28 @@ def run_tp_bench(args, wl, dtype, device, rank, world):
         dist.barrier()
     dt = time.time() - t0
     tokens = eng.num_nodes - start
+    return {"ms_per_step": round(dt / args.steps * 1e3, 4), "tokens_per_s_raw_draft": round(tokens / dt, 2),
+            "accept_len_raw_draft": round(tokens / args.steps, 3), "n_ranks_rccl": world,
+            "backend": dist.get_backend() if dist.is_initialized() else "none",
+            "allreduces_per_verify": 2 * cfg.num_hidden_layers, "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4,
+            "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 tile per "
+                           "layer; draft replicated", "tree": "3x4", "scaling": "strong"}
+
+
+def run_tp_bench(args, wl, dtype, device, rank, world):
+    """bench.py --parallel tp: the tensor-parallel engine alone, one JSON line from rank 0."""
+    import json
+
+    import torch.distributed as dist
+    r = tp_measure(args, wl, dtype, device, rank, world)
     out = None
     if rank == 0:
-        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": round(tokens / dt, 2), "unit": "tokens/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s_raw_draft"], "unit": "tokens/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
                "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
-               "config": {"workload": wl["desc"], "parallelism": f"tp{world}: heads / MLP width / vocabulary split, "
-                          "2 RCCL all-reduces of [T, H] fp32 per layer", "tree": "3x4", "prompt_len": args.prompt_len},
-               "accept_len": round(tokens / args.steps, 3)}
+               "config": {"workload": wl["desc"], "parallelism": r["parallelism"], "tree": "3x4", "prompt_len": args.prompt_len},
+               "accept_len": r["accept_len_raw_draft"], "tp": r}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():                                  # also the 1-rank group bench.py opens for the RCCL smoke run
         if world > 1:
