@@ -296,6 +296,25 @@ typedef struct UmbStep {
  * fp32 logits land in ws->logits. */
 int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, umb_stream_t stream);
 
+/* Tensor-parallel forward (no reference counterpart -- the reference has no distributed code): `m` is
+ * this rank's 1/world shard of the model (q/k/v and gate/up column-split by head / MLP column, o and down row-split,
+ * lm_head vocabulary-split; embedding, norms and the residual stream replicated).  After each row-split GEMM the
+ * library calls `allreduce(ctx, buf, count, stream)`: sum `count` fp32 values at `buf` over all ranks, in place, ordered
+ * on `stream` (RCCL ncclAllReduce on that stream -- capturable into a hipGraph like every kernel of the forward -- or
+ * any other transport); non-zero return aborts the forward with -5.  Two calls per layer; world == 1 (or a NULL
+ * descriptor): none, identical to umb_model_forward.  Needs ws->fused == 0 (the 8-launch schedule).  The logits of rows
+ * [head_from, T) land in ws->logits as [rows][lm_head.N] = this rank's vocabulary slice. */
+typedef int (*umb_allreduce_fn)(void* ctx, float* buf, int64_t count, umb_stream_t stream);
+typedef struct UmbTP {
+  int32_t rank, world;
+  umb_allreduce_fn allreduce;
+  void* ctx;
+} UmbTP;
+int umb_model_forward_tp(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbTP* tp,
+                         umb_stream_t stream);
+/* partial[0][i] += partial[1][i] + ... + partial[S-1][i] for i < n, in split order (the fixed order every reduce here uses) */
+int umb_sum_splits(float* partial, int S, int64_t n, umb_stream_t stream);
+
 /* LlamaOffload / LlamaAwqOffload.inference (llama.py:196-219): layers whose weights live in pinned
  * host slabs are streamed into two device slabs on copy_stream, event-ordered against compute.
  * host_slabs[l] == NULL -> layer l is device resident (its UmbLayer pointers are used as is);

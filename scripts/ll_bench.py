@@ -110,7 +110,7 @@ def bench_forward(name, layers, T, dtype):
     from umbrella_amd.models.config import KNOWN
     from umbrella_amd.models.llama import Llama
     res = {}
-    for sched in ("split", "ll"):
+    for sched in os.environ.get("SCHEDS", "split,ll").split(","):
         os.environ["UMB_SCHED"] = sched
         cfg = copy.copy(KNOWN[name])
         cfg.num_hidden_layers = layers
@@ -141,8 +141,9 @@ def bench_forward(name, layers, T, dtype):
         wb = m.weight_bytes()
         del m, g
         torch.cuda.empty_cache()
-    print(f"forward {name} L={layers} T={T}: split {res['split']:.3f} ms | ll {res['ll']:.3f} ms | weights {wb/1e9:.2f} GB "
-          f"-> {wb/res['ll']/1e6:.0f} GB/s (ll)", flush=True)
+    best = min(res.values())
+    print(f"forward {name} L={layers} T={T}: " + " | ".join(f"{k} {v:.3f} ms" for k, v in res.items()) +
+          f" | weights {wb/1e9:.2f} GB -> {wb/best/1e6:.0f} GB/s (best)  [UMB_PF_MB={os.environ.get('UMB_PF_MB', 'default')}]", flush=True)
 
 
 def bench_stream():

@@ -86,17 +86,29 @@ def _run_pair(target_name, draft_name, dtype, tree, acc, dev):
     assert tg == te, "hipGraph replay and eager launches disagree"
     assert len(tg) >= NEW
     exact = _check_against_ar(target, prompt, tg, tol, dev, "raw draft")
-    # (3) the tree exercised: the target's own continuation steered into the tree
-    assert eg._prefill(torch.tensor([prompt]))
-    start = eg.num_nodes
-    eg.set_oracle_draft(ar, start, acc, seed=0)
-    steps = 0
-    while eg.num_nodes - start < NEW and eg.validate_status():
-        eg.step()
-        steps += 1
-    tk = eg.tokens[start:eg.num_nodes + 1].tolist()
-    accept = (eg.num_nodes - start) / max(steps, 1)
-    eg.reset()
+    # (3) the tree exercised: the target's own continuation steered into the tree.  A token verified as a depth-d tree
+    # node sums its attention in another order than the same token verified as a root, so a 16-bit near-tie can move
+    # the steered run off the recorded continuation (after which nothing is accepted any more): as bench.py does, the
+    # continuation is re-recorded under the knob's own execution pattern until it is a fixed point.
+    truth = ar
+    for _ in range(8):
+        assert eg._prefill(torch.tensor([prompt]))
+        start = eg.num_nodes
+        eg.set_oracle_draft(truth, start, acc, seed=0)
+        steps = 0
+        while eg.num_nodes - start < NEW and eg.validate_status():
+            eg.step()
+            steps += 1
+        accept = (eg.num_nodes - start) / max(steps, 1)
+        div = eg.diverged
+        while eg.num_nodes - start < NEW + 16 and eg.validate_status():
+            eg.step()
+        tk = eg.tokens[start:start + NEW + 1].tolist()
+        truth = eg.tokens[start:eg.num_nodes + 1].tolist()
+        eg.reset()
+        if div == 0:
+            break
+    assert div == 0, "the steered continuation never became a fixed point"
     exactk = _check_against_ar(target, prompt, tk, tol, dev, "steered draft")
     same = next((i for i in range(min(len(tg), len(ar))) if tg[i] != ar[i]), min(len(tg), len(ar)))
     return dict(n=len(tg), exact=exact, nk=len(tk), exactk=exactk, accept=accept, same_as_free_ar=same,

@@ -78,6 +78,13 @@ class UmbStep(C.Structure):
                 ("layer_begin", C.c_int32), ("layer_end", C.c_int32), ("skip_embed", C.c_int32)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class UmbTP(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p)]
+
+
 class UmbOffload(C.Structure):
     _fields_ = [("host_slabs", C.POINTER(C.c_void_p)), ("slab_bytes", C.c_size_t), ("dev_slab", C.c_void_p * 2),
                 ("copy_stream", C.c_void_p), ("ev_copied", C.c_void_p * 2), ("ev_free", C.c_void_p * 2),
@@ -123,6 +130,8 @@ SIGNATURES = {
     "umb_write_token": [_P, _P, _P, _P],
     "umb_apply_override": [_P, _P, _P, _I, _I, _P],
     "umb_model_forward": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), _P],
+    "umb_model_forward_tp": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), C.POINTER(UmbTP), _P],
+    "umb_sum_splits": [_P, _I, C.c_int64, _P],
     "umb_model_forward_offload": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep),
                                   C.POINTER(UmbOffload), _P],
     "umb_bench_launch": [_I, _I, _P, _P],

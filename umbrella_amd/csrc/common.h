@@ -58,6 +58,15 @@ struct F16 {
 };
 
 template <typename P> __device__ __forceinline__ float rnd(float f) { return P::to_f(P::from_f(f)); }
+// x * y rounded to the model dtype and made opaque to the optimiser.  hipcc compiles device code with -ffp-contract=fast
+// and folds fptrunc(fpext(a) * fpext(c)) back to half arithmetic: rnd(a * c) + rnd(b * s) on fp16 then becomes
+// v_fma_f16(a, c, b * s) -- ONE rounding where eager torch (apply_rotary_pos_emb, model_utils.py:50-51) performs two.
+// The empty asm keeps the rounded product a value of its own.
+template <typename P> __device__ __forceinline__ float mul_rnd(float x, float y) {
+  float p = rnd<P>(x * y);
+  asm volatile("" : "+v"(p));
+  return p;
+}
 template <typename P> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)P::from_f(lo) | ((unsigned)P::from_f(hi) << 16);
 }

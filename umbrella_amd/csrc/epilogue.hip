@@ -250,8 +250,8 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
       // rotate-half RoPE in the model dtype (each product and the sum are rounded, as eager torch does)
       const float c0 = P::to_f(cosT[(long)p * D + d]), c1 = P::to_f(cosT[(long)p * D + d + half]);
       const float s0 = P::to_f(sinT[(long)p * D + d]), s1 = P::to_f(sinT[(long)p * D + d + half]);
-      const float o0 = rnd<P>(rnd<P>(a * c0) + rnd<P>(-b * s0));
-      const float o1 = rnd<P>(rnd<P>(b * c1) + rnd<P>(a * s1));
+      const float o0 = rnd<P>(mul_rnd<P>(a, c0) + mul_rnd<P>(-b, s0));
+      const float o1 = rnd<P>(mul_rnd<P>(b, c1) + mul_rnd<P>(a, s1));
       if (head < Hq) {
         u16* qo = q_out + ((long)t * Hq + head) * D;
         qo[d] = P::from_f(o0); qo[d + half] = P::from_f(o1);
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(64) void rope_inplace_kernel(u16* __restrict__ q, u
     const float c0 = P::to_f(cosT[cb + d]), c1 = P::to_f(cosT[cb + d + half]);
     const float s0 = P::to_f(sinT[cb + d]), s1 = P::to_f(sinT[cb + d + half]);
     // x * cos + rotate_half(x) * sin in the model dtype: every product and the sum are rounded, as eager torch does
-    base[d] = P::from_f(rnd<P>(a * c0) + rnd<P>(-b * s0));
-    base[d + half] = P::from_f(rnd<P>(b * c1) + rnd<P>(a * s1));
+    base[d] = P::from_f(mul_rnd<P>(a, c0) + mul_rnd<P>(-b, s0));
+    base[d + half] = P::from_f(mul_rnd<P>(b, c1) + mul_rnd<P>(a, s1));
   }
 }
 
@@ -355,6 +355,15 @@ __global__ __launch_bounds__(64) void kv_append_kernel(u16* __restrict__ kc, u16
   for (int d = threadIdx.x; d < D; d += 64) {
     kd[d] = ks[d];
     vd[(long)d * LV] = vs[d];
+  }
+}
+
+// ---- partial[0] += partial[1] + ... + partial[S-1], split order (tensor-parallel wide forwards: one slab per all-reduce)
+__global__ __launch_bounds__(256) void sum_splits_kernel(float* __restrict__ part, int S, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+    for (int s = 1; s < S; ++s) a += reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i];
+    reinterpret_cast<f32x4*>(part)[i] = a;
   }
 }
 
@@ -457,5 +466,15 @@ extern "C" int umb_h2d_layer(void* dst, const void* src_pinned, size_t bytes, hi
   if (ev_free && hipStreamWaitEvent(copy_stream, (hipEvent_t)ev_free, 0) != hipSuccess) return UMB_EHIP;
   if (hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, copy_stream) != hipSuccess) return UMB_EHIP;
   if (ev_copied && hipEventRecord((hipEvent_t)ev_copied, copy_stream) != hipSuccess) return UMB_EHIP;
+  return UMB_OK;
+}
+
+extern "C" int umb_sum_splits(float* partial, int S, int64_t n, hipStream_t st) {
+  if (!partial || S < 1 || n < 0 || (n & 3)) return UMB_EINVAL;
+  if (S == 1 || n == 0) return UMB_OK;
+  const long n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(sum_splits_kernel, dim3(grid), dim3(256), 0, st, partial, S, n4);
+  UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

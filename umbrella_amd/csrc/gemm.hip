@@ -581,10 +581,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
         const unsigned sl_ = *reinterpret_cast<const unsigned*>(fx.sinT + cb + m);
         const unsigned sh = *reinterpret_cast<const unsigned*>(fx.sinT + cb + m + half);
         // rotate-half in the model dtype: every product and the sum are rounded (eager torch, model_utils.py:50-51)
-        const float lo0 = rnd<P>(rnd<P>(a0 * lo_f<P>(cl)) + rnd<P>(-b0 * lo_f<P>(sl_)));
-        const float lo1 = rnd<P>(rnd<P>(a1 * hi_f<P>(cl)) + rnd<P>(-b1 * hi_f<P>(sl_)));
-        const float hi0 = rnd<P>(rnd<P>(b0 * lo_f<P>(ch)) + rnd<P>(a0 * lo_f<P>(sh)));
-        const float hi1 = rnd<P>(rnd<P>(b1 * hi_f<P>(ch)) + rnd<P>(a1 * hi_f<P>(sh)));
+        const float lo0 = rnd<P>(mul_rnd<P>(a0, lo_f<P>(cl)) + mul_rnd<P>(-b0, lo_f<P>(sl_)));
+        const float lo1 = rnd<P>(mul_rnd<P>(a1, hi_f<P>(cl)) + mul_rnd<P>(-b1, hi_f<P>(sl_)));
+        const float hi0 = rnd<P>(mul_rnd<P>(b0, lo_f<P>(ch)) + mul_rnd<P>(a0, lo_f<P>(sh)));
+        const float hi1 = rnd<P>(mul_rnd<P>(b1, hi_f<P>(ch)) + mul_rnd<P>(a1, hi_f<P>(sh)));
         u16* dst = (head < fx.Hq) ? fx.q_out + ((long)tok * fx.Hq + head) * D
                                   : fx.kc + ((long)(head - fx.Hq) * fx.Lmax + sl) * D;
         *reinterpret_cast<unsigned*>(dst + m) = pack2<P>(lo0, lo1);

@@ -57,11 +57,26 @@ static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
                         ws->hw, first_norm, ws->ssq, ws->ssq_stride, m->dtype, st);
 }
 
+// ---- tensor parallelism: this rank holds 1/P of every linear (q/k/v, gate/up column-split; o, down
+// row-split), so the fp32 partial sums of the two row-split GEMMs are summed over the ranks before the residual reduce.
+// The collective is the caller's (RCCL all-reduce on `st`, captured into the iteration's hipGraph like every kernel
+// here; host-staged gloo in the CPU-side tests): two calls per layer.  Small tiles (<= 2 MiB: the T <= 64 verify) go
+// out with their split-K slabs as they are -- no extra kernel --, larger ones are summed over the splits first.
+static inline bool tp_on(const UmbTP* tp) { return tp && tp->world > 1 && tp->allreduce; }
+static int tp_allreduce(const UmbTP* tp, float* partial, int* S, long TN, hipStream_t st) {
+  if (!tp_on(tp)) return UMB_OK;
+  if ((long)*S * TN * 4 > (2l << 20) && *S > 1) {
+    CK(umb_sum_splits(partial, *S, TN, st));
+    *S = 1;
+  }
+  return tp->allreduce(tp->ctx, partial, (int64_t)*S * TN, st) ? UMB_EHIP : UMB_OK;
+}
+
 // Schedule 0 (default): one decoder layer = 8 launches; split-K partials are reduced at kernel boundaries by
 // small epilogue kernels.  Measured faster on MI355X than schedule 1: an in-kernel cross-workgroup hand-off costs
 // as much as a kernel boundary on the 8-XCD part (profiles/README.md), and it serialises a tail onto every GEMM.
 static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
-                       const void* next_norm, hipStream_t st) {
+                       const void* next_norm, hipStream_t st, const UmbTP* tp = nullptr) {
   const int T = s->T, dt = m->dtype;
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
@@ -73,12 +88,16 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
                    ws->attn_counters, dt, st));
   CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr, true));
-  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.o, T, true), T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  int So = eff_s(ly.o, T, true);
+  CK(tp_allreduce(tp, ws->partial, &So, (long)T * m->H, st));
+  CK(umb_reduce_residual_norm(ws->partial, So, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
   CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
   CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr, true));
-  CK(umb_reduce_residual_norm(ws->partial, eff_s(ly.down, T, true), T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm,
-                              m->eps, dt, st));
+  int Sd = eff_s(ly.down, T, true);
+  CK(tp_allreduce(tp, ws->partial, &Sd, (long)T * m->H, st));
+  CK(umb_reduce_residual_norm(ws->partial, Sd, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt,
+                              st));
   return UMB_OK;
 }
 
@@ -242,9 +261,20 @@ static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hip
   return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, &fh);
 }
 
-extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
+static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbTP* tp, hipStream_t st) {
   const int lb = s->layer_begin, le = s->layer_end;
   if (lb < 0 || le > m->L || lb >= le) return UMB_EINVAL;
+  if (tp_on(tp)) {
+    // row-split partial sums meet between the GEMM and its reduce kernel: the 8-launch schedule only
+    if (ws->fused != 0) return UMB_EINVAL;
+    CK(prologue(m, ws, s, m->layers[lb].norm1, st));
+    for (int l = lb; l < le; ++l) {
+      const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
+      CK(layer_split(m, ws, s, m->layers[l], l, nn, st, tp));
+    }
+    if (le == m->L) CK(head(m, ws, s, st));
+    return UMB_OK;
+  }
   const bool ll = use_ll(ws, s);
   int sg = 4;
   CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st));
@@ -254,6 +284,16 @@ extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, cons
   }
   if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
+}
+
+extern "C" int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
+  return model_forward(m, ws, s, nullptr, st);
+}
+
+extern "C" int umb_model_forward_tp(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbTP* tp,
+                                    hipStream_t st) {
+  if (tp && (tp->world < 1 || tp->rank < 0 || tp->rank >= tp->world)) return UMB_EINVAL;
+  return model_forward(m, ws, s, tp, st);
 }
 
 // ---- offload: double-buffered layer streaming, event ordered (no device-wide syncs)
