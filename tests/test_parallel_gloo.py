@@ -38,6 +38,7 @@ def _worker(rank, world, port, q):
     P, start, chunk = 7, 100, 4
     if rank == 0:
         comm.plan(OP_PREFILL, P, start, 1, chunk)
+        comm.bcast(torch.arange(700, 700 + P, dtype=torch.int32))   # the prompt's token ids follow their plan
         for lo in range(0, P, chunk):
             rows = min(P, lo + chunk) - lo
             h = torch.full((rows, H), 10.0)
@@ -48,13 +49,15 @@ def _worker(rank, world, port, q):
         for it in range(3):
             if it:                                               # commit of the previous iteration + "one more follows"
                 comm.share_commit(torch.tensor([2, 9, 0, 50 + it - 1, 3, 0, 0, 0], dtype=torch.int32),
-                                  torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=1)
+                                  torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=1,
+                                  newtok=torch.tensor([41, 42, 9], dtype=torch.int32))
             h = torch.full((T, H), float(it + 1))
             h[:, 0] = torch.arange(T)
             comm.send_activations(h + 1.0)
             log.append(comm.return_ids(n=T).tolist())
         comm.share_commit(torch.tensor([2, 9, 0, 52, 3, 0, 0, 0], dtype=torch.int32),
-                          torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=0)
+                          torch.tensor([0, 2, 5, 0, 0], dtype=torch.int32), cont=0,
+                          newtok=torch.tensor([43, 44, 9], dtype=torch.int32))
         comm.plan(OP_STOP)
         q.put(("rank0", log))
     else:
@@ -65,6 +68,9 @@ def _worker(rank, world, port, q):
                 break
             if c[0] == OP_PREFILL:
                 Pp, st, want, ch = c[1], c[2], c[3], c[4]
+                ids = torch.zeros(Pp, dtype=torch.int32)
+                comm.bcast(ids)
+                log.append(("ids", ids.tolist()))
                 for lo in range(0, Pp, ch):
                     rows = min(Pp, lo + ch) - lo
                     h = comm.recv_activations(rows, into=own)
@@ -82,8 +88,9 @@ def _worker(rank, world, port, q):
                     comm.send_activations(h)
                     if comm.last:
                         comm.return_ids((h[:, 0] + h[:, 1]).int(), T)
-                    res, path, cont = comm.share_commit()
-                    log.append(("commit", res.tolist(), path.tolist(), cont))
+                    res, path, newtok, cont = comm.share_commit()
+                    assert comm.commit_host[:5] == res.tolist()[:5]
+                    log.append(("commit", res.tolist(), path.tolist(), cont, newtok.tolist()))
         q.put((f"rank{rank}", log))
     dist.barrier()
     dist.destroy_process_group()
@@ -112,3 +119,5 @@ def test_pipeline_protocol_gloo(world):
         commits = [e for e in log if e[0] == "commit"]
         assert [c[3] for c in commits] == [1, 1, 0]                # two "continue", then leave the decode loop
         assert commits[1][1][:5] == [2, 9, 0, 51, 3] and commits[1][2] == [0, 2, 5, 0, 0]
+        assert commits[0][4][:3] == [41, 42, 9] and commits[2][4][:3] == [43, 44, 9] and len(commits[0][4]) == 6
+        assert [e for e in log if e[0] == "ids"] == [("ids", list(range(700, 707)))]

@@ -1,6 +1,7 @@
 """Layer-sharded pipeline with REAL HIP stages: two processes share one GPU, gloo carries the hops (through pinned host
 buffers -- RCCL needs one GPU per rank, which the test box does not have).  Token ids must equal the single-process
-engine's: same kernels, same order, only the transport differs."""
+engine's: same kernels, same order, only the transport differs -- for the static greedy engine (BASELINE config 5) and
+for the reference's 70B engine: dynamic beam-grown tree with stochastic verification, sampled on the last stage."""
 import os
 import socket
 
@@ -70,3 +71,63 @@ def test_two_stage_pipeline_equals_single_process():
     assert all(p.exitcode == 0 for p in procs)
     assert stage_layers == 8                                          # 16 layers split 8 / 8
     assert a == ra and b == rb
+
+
+DYN = dict(width=8, num_beams=8, depth=4, temperature=0.7, topp=0.9, topk=16, repetition_penalty=1.05)
+
+
+def _pp_dynamic_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as ge
+    ge.build()
+    from umbrella_amd.parallel import PipelinedDynamicEngine, build_pipelined_engine, shutdown_pipeline
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    eng = build_pipelined_engine("cuda:0", dtype=torch.float16, seed=11, engine="dynamic", model=NAME, draft_model=NAME,
+                                 max_length=512, exit_layer=4, safe_buffer=16, tokenizer=IdTokenizer(), **DYN)
+    if eng is not None:
+        assert isinstance(eng, PipelinedDynamicEngine)
+        a = eng.generate(input_ids=PROMPT, max_new_tokens=20)["generated_tokens"]
+        g = eng.generate(input_ids=PROMPT, max_new_tokens=12, temperature=0.0, repetition_penalty=1.0)["generated_tokens"]
+        b = eng.generate(input_ids=PROMPT, max_new_tokens=12, temperature=0.7, repetition_penalty=1.05)["generated_tokens"]
+        shutdown_pipeline(eng)
+        q.put((a, g, b))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_stage_dynamic_stochastic_equals_single_process():
+    """dynamic w8/b8/d4 (T = 33), temperature 0.7 / top-p 0.9 / top-k 16 / penalty 1.05, seed 11: the last stage samples
+    with umb_sample_rows over its own copy of the token history; ids equal the single-process engine's draw for draw.
+    Then the knobs change between requests (greedy, back to stochastic): the stages follow through the OP_DECODE plan."""
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")
+    from umbrella_amd.speculation.dynamic_speculation_engine import DynamicSpeculationEngine
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    ref = DynamicSpeculationEngine(NAME, NAME, dtype=torch.float16, device="cuda:0", max_length=512, exit_layer=4,
+                                   safe_buffer=16, tokenizer=IdTokenizer(), offload=False, seed=11, **DYN)
+    ref.initialize()
+    ra = ref.generate(input_ids=PROMPT, max_new_tokens=20)["generated_tokens"]
+    rg = ref.generate(input_ids=PROMPT, max_new_tokens=12, temperature=0.0, repetition_penalty=1.0)["generated_tokens"]
+    rb = ref.generate(input_ids=PROMPT, max_new_tokens=12, temperature=0.7, repetition_penalty=1.05)["generated_tokens"]
+    del ref
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pp_dynamic_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        a, g, b = q.get(timeout=200)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert a == ra and g == rg and b == rb
+    assert len(a) >= 20

@@ -2,8 +2,11 @@
 
 CPU: the sharding helpers against the unsharded oracle -- algebra per linear (dense and AutoAWQ tensors) and a
 world-2 gloo run of a whole tiny-model forward with all-reduces where the module puts them.
-GPU (single process, LocalComm: the all-reduce is a sum over the in-process shards): HIP shards reproduce the
-unsharded HIP model up to fp32 summation order; the engine emits the fp32 oracle's greedy tokens."""
+GPU: (a) two PROCESSES sharing the box's one GPU, each holding one shard, the all-reduce hook of the native layer
+chain answered over host-staged gloo: logits equal the unsharded HIP model's up to fp32 summation order, the static
+(greedy) and dynamic (stochastic) engines emit identical tokens on both ranks and greedy ones are the fp32 oracle's
+choices; (b) RCCL itself in a 1-rank group with the hook forced on: the collectives are captured into the iteration
+hipGraph and the tokens equal the plain engine's bit for bit."""
 import os
 import socket
 
@@ -94,19 +97,19 @@ def _tp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from umbrella_amd.tensor_parallel import DistComm
+    from umbrella_amd.tensor_parallel import TPComm
     cfg = _cfg()
     sd = synth_state_small(cfg, G["seeds"]["target"])
-    comm = DistComm()
+    comm = TPComm()
     local = shard_state_dict(sd, cfg, rank, world)
     n = 12
     ids = torch.tensor(G["cases"]["static_3x4"]["prompt"][:n])
     pos = torch.arange(n)
     mask = torch.tril(torch.ones(n, n, dtype=torch.bool))
-    logits = _tp_forward_torch(cfg, local, rank, world, ids, pos, mask, lambda t: comm.all_reduce([t]))
-    vals, idx = logits.max(dim=-1)
-    best = comm.gather_max([vals], [idx.int()], cfg.vocab_size // world)[0]
-    q.put((rank, logits, best))
+    logits = _tp_forward_torch(cfg, local, rank, world, ids, pos, mask, comm.all_reduce)
+    full = torch.empty(n, cfg.vocab_size)
+    comm.all_gather_columns(logits.contiguous(), full)
+    q.put((rank, logits, full.argmax(-1)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,20 +138,12 @@ def test_tp_forward_gloo_world2():
         assert torch.equal(g[2].long(), ref.argmax(-1))
 
 
-# ------------------------------------------------------------------ GPU: HIP shards in one process
+# ------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def dev():
     import __graft_entry__ as ge
     ge.build()
     return torch.device("cuda:0")
-
-
-def _build_tp(dev, dtype, awq, world, max_length=256):
-    from umbrella_amd.tensor_parallel import LocalComm, TensorParallelLlama
-    cfg = _cfg(awq=awq)
-    sd = synth_awq_small(cfg, G["seeds"]["target"]) if awq else synth_state_small(cfg, G["seeds"]["target"])
-    tp = TensorParallelLlama.build(cfg, sd, world, LocalComm(world), max_length, str(dev), dtype, ranks=list(range(world)))
-    return tp, cfg, sd
 
 
 @pytest.mark.gpu
@@ -172,35 +167,51 @@ def test_tp_partials_sum_to_unsplit_linear(dev, awq):
         base = "model.layers.0." + name
         n, k = linear_shapes(cfg)[name]
         x = (torch.randn(13, k, device=dev, generator=gen) * 0.5).to(dtype)
-        full = packed(sd, base).apply_ll(x)
-        parts = sum(packed(s, base).apply_ll(x[:, lo:hi].contiguous())
+        full = packed(sd, base).apply(x)
+        parts = sum(packed(s, base).apply(x[:, lo:hi].contiguous())
                     for s, (lo, hi) in zip(shards, (shard_range(k, r, world) for r in range(world))))
         assert float((parts - full).abs().max()) <= 2e-5 * float(full.abs().max()) + 1e-6
     base = "model.layers.0.mlp.gate_proj"
     n, k = linear_shapes(cfg)["mlp.gate_proj"]
     x = (torch.randn(13, k, device=dev, generator=gen) * 0.5).to(dtype)
-    full = packed(sd, base).apply_ll(x)
-    cat = torch.cat([packed(s, base).apply_ll(x) for s in shards], dim=-1)
+    full = packed(sd, base).apply(x)
+    cat = torch.cat([packed(s, base).apply(x) for s in shards], dim=-1)
     assert torch.equal(cat, full)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("awq", [False, True])
-def test_tp_model_matches_unsharded_model(dev, awq):
-    """Prefix + a 13-node tree through two HIP shards (LocalComm) vs the unsharded HIP model: same arg-max ids wherever
-    the unsharded fp32-rounded logits have a clear margin, and the residual streams agree to 16-bit noise."""
+PROMPT = G["cases"]["static_3x4"]["prompt"]
+
+
+def _tp_gpu_worker(rank, world, port, q, awq):
+    """one tensor-parallel rank on cuda:0 (both ranks share the GPU): gloo carries the collectives through the host"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as ge
+    ge.build()
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from hip_helpers import growmap, hip_model
     from umbrella_amd.models.llama import pack_mask_bits
-    dtype = torch.float16
-    tp, cfg, sd = _build_tp(dev, dtype, awq, 2)
+    from umbrella_amd.speculation.dynamic_speculation_engine import DynamicSpeculationEngine
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm
+    dev, dtype = torch.device("cuda:0"), torch.float16
+    cfg = _cfg(awq=awq)
+    sd = synth_awq_small(cfg, G["seeds"]["target"]) if awq else synth_state_small(cfg, G["seeds"]["target"])
+    comm = TPComm()
+    assert comm.world == world and comm.staged
+    tp = TensorParallelLlama.build(cfg, sd, comm, 256, str(dev), dtype)
+    assert tp.m.config.num_attention_heads == cfg.num_attention_heads // world and tp.m.lm_head.N == cfg.vocab_size // world
+    # ---- model level: prefix + a 13-node tree vs the unsharded HIP model
     full, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, awq=awq)
     gm = growmap("3x4")
     P, T = 24, gm["size"]
-    prompt = torch.tensor(G["cases"]["static_3x4"]["prompt"][:P], dtype=torch.int32, device=dev)
+    prompt = torch.tensor(PROMPT[:P], dtype=torch.int32, device=dev)
     tree = torch.randint(6, 500, (T,), dtype=torch.int32, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
-    first = tp.prefill_tokens(prompt, 0)
-    row = full.prefill_tokens(prompt, 0)
-    assert int(first) == int(row.argmax())
+    row_tp = tp.prefill_tokens(prompt, 0).clone()
+    row = full.prefill_tokens(prompt, 0).clone()
     tokens = torch.zeros(256 + T + 8, dtype=torch.int32, device=dev)
     tokens[:P] = prompt
     tokens[P:P + T] = tree
@@ -209,35 +220,107 @@ def test_tp_model_matches_unsharded_model(dev, awq):
     bits = pack_mask_bits((torch.tensor(gm["mask"]) == 1).to(dev)).contiguous()
     tp.forward_tree(tokens, n_dev, depth, 0, T, bits, bits.shape[1], head_from=0)
     full.forward_tree(tokens, n_dev, depth, 0, T, bits, bits.shape[1], head_from=0)
-    ref = full.logits_buffer[:T]
-    top2 = ref.topk(2, dim=-1).values
-    clear = (top2[:, 0] - top2[:, 1]) > (0.25 if awq else 0.12)
-    assert int(clear.sum()) >= T // 2
-    assert torch.equal(tp.sampled_ids[:T][clear].long(), ref.argmax(-1)[clear])
-    h_tp, h_full = tp.shards[0]._bufs["h"][:T].float(), full._bufs["h"][:T].float()
-    assert torch.equal(tp.shards[0]._bufs["h"][:T], tp.shards[1]._bufs["h"][:T])      # the residual stream is replicated
-    assert float((h_tp - h_full).abs().max()) <= 0.03 * float(h_full.abs().max())
+    d_prefill = float((row_tp - row).abs().max())
+    d_tree = float((tp.logits_buffer[:T] - full.logits_buffer[:T]).abs().max())
+    h_same = float((tp.m._bufs["h"][:T].float() - full._bufs["h"][:T].float()).abs().max())
+    tp.clear()
+    del full
+    # ---- engines: the ordinary classes over the tensor-parallel target
+    draft, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, awq=awq, cuda_graph=True)
+    se = StaticSpeculationEngine("tiny-draft", "tiny-target", dtype=dtype, device=str(dev), growmap=gm, max_length=256,
+                                 safe_buffer=16, stop_distance=8, draft_model_obj=draft, target_model_obj=tp,
+                                 tokenizer=IdTokenizer(), hip_graph=False)
+    se.initialize()
+    o1 = se.generate(input_ids=PROMPT, max_new_tokens=32)
+    o2 = se.generate(input_ids=PROMPT, max_new_tokens=32)
+    draft2, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, awq=awq)
+    de = DynamicSpeculationEngine("tiny-draft", "tiny-target", dtype=dtype, device=str(dev), width=8, num_beams=8, depth=4,
+                                  max_length=256, safe_buffer=16, stop_distance=8, draft_model_obj=draft2, target_model_obj=tp,
+                                  tokenizer=IdTokenizer(), offload=False, hip_graph=False, temperature=0.8, topp=0.9, topk=16,
+                                  repetition_penalty=1.05, seed=5)
+    de.initialize()
+    o3 = de.generate(input_ids=PROMPT, max_new_tokens=24)
+    q.put(dict(rank=rank, d_prefill=d_prefill, d_tree=d_tree, h=h_same, static=o1["generated_tokens"],
+               static_again=o2["generated_tokens"], accept=o1["avg_accept_tokens"], dynamic=o3["generated_tokens"]))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_tp_engine_greedy_tokens(dev):
-    """TensorParallelStaticEngine over two in-process HIP shards: every emitted token is a greedy choice of the fp32
-    oracle target, acceptance works (self-draft), and a second request on the same engine repeats the first."""
-    from hip_helpers import check_greedy, growmap, hip_model
+@pytest.mark.parametrize("awq", [False, True])
+def test_tp_two_ranks_share_one_gpu(dev, awq):
+    import torch.multiprocessing as mp
+    from hip_helpers import check_greedy
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, world, port, q, awq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda d: d["rank"])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    a, b = got
+    tol = 0.25 if awq else 0.12
+    for g in got:                                   # sharded == unsharded up to fp32 summation order / 16-bit noise
+        assert g["d_prefill"] < tol and g["d_tree"] < tol and g["h"] < 0.05, g
+    # SPMD: both ranks took every decision identically, greedy and stochastic (shared seed, identical all-gathered logits)
+    assert a["static"] == b["static"] and a["dynamic"] == b["dynamic"]
+    assert a["static"] == a["static_again"] and len(a["static"]) >= 32 and a["accept"] > 2.5
+    assert len(a["dynamic"]) >= 24
+    sd = synth_awq_small(_cfg(awq=True), G["seeds"]["target"]) if awq else synth_state_small(_cfg(), G["seeds"]["target"])
+    check_greedy(G, sd, PROMPT, a["static"], torch.float16, tol=0.12 if awq else None)
+
+
+@pytest.mark.gpu
+def test_tp_rccl_hook_inside_the_iteration_graph(dev):
+    """A 1-rank RCCL group with the all-reduce hook forced on (an all-reduce over one rank is the identity): every
+    collective of the native layer chain goes through torch.distributed "nccl" on the launch stream and is captured
+    into the iteration's hipGraph; tokens equal the plain single-GPU engine's bit for bit, and without the hook (the
+    real world-1 configuration) the path IS the plain one."""
+    import torch.distributed as dist
+    from hip_helpers import growmap, hip_model, static_engine
     from umbrella_amd.speculation.speculation_utils import IdTokenizer
-    from umbrella_amd.tensor_parallel import TensorParallelStaticEngine
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm
     dtype = torch.float16
-    tp, cfg, sd = _build_tp(dev, dtype, False, 2)
-    draft, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, cuda_graph=True)
-    eng = TensorParallelStaticEngine("tiny-draft", "tiny-target", dtype=dtype, device=str(dev), growmap=growmap("3x4"),
-                                     max_length=256, safe_buffer=16, stop_distance=8, draft_model_obj=draft, tp_target=tp,
-                                     tokenizer=IdTokenizer())
-    eng.initialize()
-    prompt = G["cases"]["static_3x4"]["prompt"]
-    out = eng.generate(input_ids=prompt, max_new_tokens=32)
-    check_greedy(G, sd, prompt, out["generated_tokens"], dtype)
-    assert out["avg_accept_tokens"] > 2.5
-    again = eng.generate(input_ids=prompt, max_new_tokens=32)
-    assert again["generated_tokens"] == out["generated_tokens"]
-    with pytest.raises(ValueError):
-        eng.update_generation_args(temperature=0.7)
+    os.environ["UMB_SCHED"] = "split"               # the reference engine on the same 8-launch schedule the TP chain uses
+    try:
+        ref_eng, _ = static_engine(G, dev, dtype, self_draft=True)
+        ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+    finally:
+        os.environ.pop("UMB_SCHED")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = _cfg()
+        sd = synth_state_small(cfg, G["seeds"]["target"])
+        for force in (True, False):
+            comm = TPComm()
+            assert comm.backend == "nccl" and not comm.staged
+            tp = TensorParallelLlama.build(cfg, sd, comm, 256, str(dev), dtype, force_hook=force)
+            calls = []
+            orig = comm.all_reduce
+            comm.all_reduce = lambda t, _o=orig: (calls.append(t.numel()), _o(t))[1]
+            draft, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, cuda_graph=True)
+            eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap=growmap("3x4"), max_length=256,
+                                          safe_buffer=16, stop_distance=8, draft_model_obj=draft, target_model_obj=tp,
+                                          tokenizer=IdTokenizer())
+            eng.initialize()
+            out = eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+            assert out == ref
+            assert eng.use_graph and eng.graph_scope == "iteration" and eng._graph is not None
+            if force:       # hook calls happen at capture time only (prefill + warm-up + capture), replays issue none
+                n_iter = cfg.num_hidden_layers * 2
+                assert len(calls) > 0 and len(calls) % n_iter == 0
+                assert len(calls) < n_iter * 8, "the collectives are replayed from the graph, not re-issued per step"
+            else:
+                assert calls == []
+    finally:
+        dist.destroy_process_group()

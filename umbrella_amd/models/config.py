@@ -40,6 +40,8 @@ class LlamaCfg:
     awq_group: int = 128
     name: str = "llama"
     attention_bias: bool = False      # q/k/v projection bias (Qwen2: umbrella/models/qwen.py:94-96)
+    embed_rows: int = 0               # rows of the embedding table when they differ from vocab_size (tensor-parallel shard:
+                                      # the table stays whole while the lm_head holds vocab_size = V / P rows); 0 = vocab_size
 
     @property
     def q_dim(self):

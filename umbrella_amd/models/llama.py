@@ -172,7 +172,7 @@ class Llama(LLMBase):
 
     def __init__(self, model_name: str, batch_size: int = 1, max_length: int = 256, device: str = "cuda:0",
                  dtype=torch.float16, offload: bool = False, cuda_graph: bool = False, state_dict=None,
-                 config: LlamaCfg | None = None, seed: int = 0) -> None:
+                 config: LlamaCfg | None = None, seed: int = 0, sched: str | None = None) -> None:
         super().__init__()
         assert batch_size == 1, "the hot path is batch 1 (README.md:22)"
         self.model_name, self.batch_size, self.device, self.dtype = model_name, batch_size, device, dtype
@@ -188,7 +188,8 @@ class Llama(LLMBase):
         # checkpoints and models of hidden size >= 4096 take "split" (70B-AWQ tree verify 2.30 vs 2.58 ms per 16 layers,
         # 8B bf16 T = 31 forward 4.51 vs 5.09 ms, since the shared kernel's weight ring stopped draining -- DESIGN.md);
         # small dense models, where launches dominate, "ll" (1B draft forward 0.77 vs 0.84 ms)
-        self.sched = os.environ.get("UMB_SCHED", "auto")
+        self.sched = sched or os.environ.get("UMB_SCHED", "auto")
+        self._tp = None                         # UmbTP descriptor: set by tensor_parallel.TensorParallelLlama on a shard
         if config is None and not os.path.isdir(model_name) and state_dict is None:
             local = _resolve_hub_snapshot(model_name)             # HF cache, offline
             if local is not None:
@@ -315,7 +316,8 @@ class Llama(LLMBase):
             reseed.manual_seed(self._seed * 1000003)
         # checkpoints may carry more rows than config.vocab_size (Qwen2.5 7B+: 152064 rows, vocabulary 151936): the
         # logits buffer, arg-max, top-k and sampling all work on V columns, so both matrices are cut to V rows
-        self.embed_tokens = fetch("model.embed_tokens.weight", (V, H), "embed")[:V].to(dt).contiguous() \
+        Ve = getattr(c, "embed_rows", 0) or V      # tensor-parallel shard: whole table, V / P head rows
+        self.embed_tokens = fetch("model.embed_tokens.weight", (Ve, H), "embed")[:Ve].to(dt).contiguous() \
             if (self.is_first or (self.is_last and c.tie_word_embeddings)) else None
         if self.is_last:
             head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head")[:V].to(dt)
@@ -384,7 +386,7 @@ class Llama(LLMBase):
         m = self._m
         m.dtype, m.L, m.H, m.I, m.Hq, m.Hkv, m.D, m.V, m.Lmax = (_lib.dtype_code(dt), L, H, c.intermediate_size,
                                                                c.num_attention_heads, c.num_key_value_heads,
-                                                               c.head_dim, V, self.max_length)
+                                                               c.head_dim, Ve, self.max_length)   # V: rows of the embedding table
         m.eps, m.attn_scale = c.rms_norm_eps, 1.0 / math.sqrt(c.head_dim)
         m.embed = self.embed_tokens.data_ptr() if (self.embed_tokens is not None and self.is_first) else 0
         if self.is_last:
@@ -478,7 +480,10 @@ class Llama(LLMBase):
     def _run(self, step: UmbStep):
         lib = _lib.load()
         st = _lib.stream_ptr()
-        if self._off is not None:
+        if self._tp is not None:
+            assert self._off is None, "tensor-parallel shards are device resident"
+            rc = lib.umb_model_forward_tp(C.byref(self._m), C.byref(self._ws), C.byref(step), C.byref(self._tp), st)
+        elif self._off is not None:
             rc = lib.umb_model_forward_offload(C.byref(self._m), C.byref(self._ws), C.byref(step), C.byref(self._off), st)
         else:
             rc = lib.umb_model_forward(C.byref(self._m), C.byref(self._ws), C.byref(step), st)

@@ -14,9 +14,13 @@ Protocol.  Stage ranks follow a fixed op schedule; rank 0 speaks only at mode ch
                                                                     causal chunks: recv -> forward -> send
                                 [OP_DECODE]                         enter the decode loop
                                 [OP_RESET] / [OP_STOP]
-    decode loop, per iteration: recv [T, H] -> forward_tree (hipGraph) -> send; last stage: arg-max -> ids to rank 0;
-                                then ONE broadcast int32[8 + max_path] = accept result + path + `cont` flag:
-                                KV compaction, and cont = 0 leaves the loop (back to waiting for a plan).
+                                [OP_DECODE, sampling knobs]         (greedy flag, temperature, top-p, penalty, top-k, seed)
+    decode loop, per iteration: (dynamic trees: ONE broadcast of the beam-grown mask rows) recv [T, H] -> forward_tree
+                                (hipGraph) -> send; last stage: arg-max, or umb_sample_rows over its own copy of the token
+                                history -> T ids to rank 0; then ONE broadcast int32[8 + 2 max_path + 1] = accept result +
+                                path + the tokens committed by this iteration + `cont` flag: KV compaction, history
+                                update, and cont = 0 leaves the loop (back to waiting for a plan).
+    A prompt's token ids follow their OP_PREFILL plan in one broadcast (the last stage penalises repetitions over them).
 Rank 0 defers the commit of iteration i until it knows what follows (the next step(): cont = 1; reset / new
 prompt / shutdown: cont = 0), so the decode loop costs exactly one collective per iteration besides the hops, and a
 stage rank reads back one word per iteration (the flag).  Activations are received straight into the stage model's
@@ -55,8 +59,10 @@ class PipelineComm:
         cdev = "cpu" if self.host_staging else device
         self.ctrl = torch.zeros(8, dtype=torch.int64, device=cdev)
         self.ids = torch.zeros(max_tokens, dtype=torch.int32, device=device)
-        self.commit = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=cdev)
-        self.commit_dev = torch.zeros(8 + max(max_path, 1), dtype=torch.int32, device=device)
+        self.max_path = max(max_path, 1)
+        n_commit = 8 + 2 * self.max_path + 1                  # accept result | path | committed tokens (kept + bonus)
+        self.commit = torch.zeros(n_commit, dtype=torch.int32, device=cdev)
+        self.commit_dev = torch.zeros(n_commit, dtype=torch.int32, device=device)
         self.h = torch.zeros(max_tokens, hidden, dtype=dtype, device=device)      # only used when no model buffer is given
         if self.host_staging:
             self._h_host = torch.zeros(max_tokens, hidden, dtype=dtype).pin_memory()
@@ -79,6 +85,19 @@ class PipelineComm:
         return self.ctrl.tolist()
 
     command = plan                                                # legacy name
+
+    def bcast(self, t: torch.Tensor):
+        """rank 0's `t` -> every rank's `t` (device tensor; host staged under gloo)"""
+        if self.world == 1:
+            return t
+        if self.host_staging:
+            h = t.cpu() if self.first else torch.empty(t.shape, dtype=t.dtype)
+            dist.broadcast(h, src=0)
+            if not self.first:
+                t.copy_(h)
+        else:
+            dist.broadcast(t, src=0)
+        return t
 
     def _recv(self, buf, host, src):
         if self.host_staging:
@@ -119,21 +138,31 @@ class PipelineComm:
             return self.ids[:n]
         return None
 
-    def share_commit(self, res=None, path=None, cont=1):
-        """rank 0: accept result (int32[8]) + path + continue flag -> every stage.  Returns (res, path, cont) views of
-        the device copy (what the compaction kernel reads)."""
+    def share_commit(self, res=None, path=None, cont=1, newtok=None):
+        """rank 0: accept result (int32[8]) + path + the tokens this iteration committed (positions n_old .. n_new: the
+        kept nodes and the bonus token) + continue flag -> every stage.  Returns (res, path, newtok, cont): views of the
+        device copy (what the compaction kernel reads)."""
+        mp = self.max_path
         if self.first:
             self.commit_dev[:8] = res[:8]
-            self.commit_dev[8:8 + path.numel()] = path
+            self.commit_dev[8:8 + mp].zero_()
+            self.commit_dev[8:8 + min(mp, path.numel())] = path[:mp]
+            if newtok is not None:
+                self.commit_dev[8 + mp:8 + mp + newtok.numel()] = newtok
             self.commit_dev[COMMIT_CONT] = cont
             if self.host_staging:
                 self.commit.copy_(self.commit_dev)
         src = self.commit if self.host_staging else self.commit_dev
-        dist.broadcast(src, src=0)
+        if self.world > 1:
+            dist.broadcast(src, src=0)
         if self.host_staging and not self.first:
             self.commit_dev.copy_(self.commit)
-        flag = int(src[COMMIT_CONT]) if not self.first else cont
-        return self.commit_dev[:8], self.commit_dev[8:], flag
+        if self.first:
+            flag = cont
+        else:
+            self.commit_host = src[:8].tolist()       # ONE read-back per iteration on a stage rank: kept, n_new, cont ...
+            flag = self.commit_host[COMMIT_CONT]
+        return self.commit_dev[:8], self.commit_dev[8:8 + mp], self.commit_dev[8 + mp:], flag
 
 
 class PipelinedTarget:
@@ -150,6 +179,10 @@ class PipelinedTarget:
 
     def reserve(self, tokens, logit_rows=None):
         self.m.reserve(tokens, logit_rows)
+
+    @property
+    def logits_buffer(self):                          # single-stage group: the head is on this rank
+        return self.m.logits_buffer
 
     def clear(self):
         self.eng._leave_decode()
@@ -181,6 +214,7 @@ class PipelinedTarget:
         self.eng._leave_decode()
         chunk = prefill_chunk(self.m)
         self.comm.plan(OP_PREFILL, P, start, int(want_logits), chunk)
+        self.comm.bcast(ids.contiguous())                   # the last stage samples over the token history
         for lo in range(0, P, chunk):
             hi = min(P, lo + chunk)
             T = hi - lo
@@ -217,21 +251,40 @@ def _capture(run, device):
     return g
 
 
+def _f2i(x: float) -> int:
+    import struct
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+def _i2f(i: int) -> float:
+    import struct
+    return struct.unpack("<f", struct.pack("<i", int(i)))[0]
+
+
 def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False, use_graph=True):
-    """Event loop of ranks > 0.  `tables` = dict(depth, mask_bits, mask_words, n_dev, eos_dev, n_eos, max_path, tree_size)."""
+    """Event loop of ranks > 0.  `tables` = dict(depth, mask_bits, mask_words, n_dev, eos_dev, n_eos, max_path, tree_size,
+    dynamic).  The last stage turns its logits into one token id per tree node -- arg-max, or umb_sample_rows (repetition
+    penalty over its own copy of the token history, top-k / top-p, temperature, a draw keyed by (seed, num_nodes, row):
+    the same kernel, arguments and seed as the single-GPU engine, so the ids are the same) -- and returns T ints."""
     from . import _lib
     dev = model.device
-    sampled = torch.zeros(comm.ids.shape[0], dtype=torch.int32, device=dev)
-    dummy_tokens = torch.zeros(model.max_length + comm.ids.shape[0] + 8, dtype=torch.int32, device=dev)
+    T = tables["tree_size"]
+    sampled = torch.zeros(max(comm.ids.shape[0], T), dtype=torch.int32, device=dev)
+    tokens = torch.zeros(model.max_length + T + 8, dtype=torch.int32, device=dev)        # the committed token history
     n_dev = tables["n_dev"]
     V = model.config.vocab_size
-    T = tables["tree_size"]
-    tree_graph = None
+    rng_state = torch.zeros(1, dtype=torch.int64, device=dev)
+    knobs = dict(greedy=1, temperature=0.0, topp=0.9, penalty=1.0, topk=32)
+    tree_graph, graph_knobs = None, None
 
     def tree_forward():
-        model.forward_tree(dummy_tokens, n_dev, tables["depth"], 0, T, tables["mask_bits"], tables["mask_words"], head_from=0)
+        model.forward_tree(tokens, n_dev, tables["depth"], 0, T, tables["mask_bits"], tables["mask_words"], head_from=0)
         if comm.last:
-            _lib.call("umb_argmax_rows", sampled, model.logits_buffer, T, V)
+            if knobs["greedy"]:
+                _lib.call("umb_argmax_rows", sampled, model.logits_buffer, T, V)
+            else:
+                _lib.call("umb_sample_rows", sampled, model.logits_buffer, T, V, tokens, n_dev, float(knobs["penalty"]),
+                          float(knobs["temperature"]), min(int(knobs["topk"]), V), float(knobs["topp"]), rng_state, 0, None, None)
 
     while True:
         c = comm.plan()
@@ -241,8 +294,10 @@ def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False, use_gr
         if op == OP_RESET:
             model.clear()
             n_dev.zero_()
+            tokens.zero_()
         elif op == OP_PREFILL:
             P, start, want, chunk = c[1], c[2], c[3], c[4]
+            comm.bcast(tokens[start:start + P])
             for lo in range(0, P, chunk):
                 hi = min(P, lo + chunk)
                 rows = hi - lo
@@ -250,18 +305,25 @@ def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False, use_gr
                 comm.recv_activations(rows, into=model.hidden_buffer)
                 pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=dev)
                 pre = torch.tensor([start + lo], dtype=torch.int32, device=dev)
-                model.forward_explicit(dummy_tokens[:rows], pos, pos, pre, head_from=(rows - 1 if last else rows))
+                model.forward_explicit(tokens[start + lo:start + hi], pos, pos, pre, head_from=(rows - 1 if last else rows))
                 comm.send_activations(model.hidden_buffer[:rows])
                 if comm.last and last:
                     row = model.logits_buffer[0]
                     if mask_first_eos and tables["n_eos"]:
                         _lib.call("umb_mask_eos", row, tables["eos_dev"], tables["n_eos"])
                     _lib.call("umb_argmax_rows", sampled[:1], row, 1, V)
+                    tokens[start + P:start + P + 1] = sampled[:1]       # the root of the first tree: part of the history
                     comm.return_ids(sampled, 1)
             n_dev.fill_(start + P)
         elif op == OP_DECODE:
+            knobs = dict(greedy=c[1], temperature=_i2f(c[2]), topp=_i2f(c[3]), penalty=_i2f(c[4]), topk=c[5])
+            rng_state.fill_(c[6])
+            if graph_knobs != tuple(sorted(knobs.items())):             # sampling knobs are launch arguments of the graph
+                tree_graph, graph_knobs = None, tuple(sorted(knobs.items()))
             cont = 1
             while cont:
+                if tables["dynamic"]:
+                    comm.bcast(tables["mask_bits"])                     # this iteration's beam-grown ancestor rows
                 comm.recv_activations(T, into=model.hidden_buffer)
                 if use_graph:
                     if tree_graph is None:
@@ -275,14 +337,19 @@ def stage_worker(model, comm: PipelineComm, tables, mask_first_eos=False, use_gr
                 comm.send_activations(model.hidden_buffer[:T])
                 if comm.last:
                     comm.return_ids(sampled, T)
-                res, path, cont = comm.share_commit()
+                res, path, newtok, cont = comm.share_commit()
                 model.kv_cache.compact(res, path.contiguous(), tables["max_path"])
+                # history: positions n_old .. n_new <- kept tokens + bonus (a no-op commit keeps nothing)
+                keep_n, n_new = comm.commit_host[0], comm.commit_host[3]
+                if keep_n > 0:
+                    tokens[n_new - keep_n:n_new + 1] = newtok[:keep_n + 1]
                 n_dev.copy_(res[3:4])
 
 
 def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **config):
-    """Layer-sharded static engine from a reference-style config (``engine: static``, ``model``, ``draft_model``,
-    ``growmap_path`` | ``growmap``, ``max_length`` ...): every rank of the default process group holds a contiguous
+    """Layer-sharded engine from a reference-style config (``engine: static`` with ``growmap_path`` | ``growmap``, or
+    ``engine: dynamic`` with ``width`` / ``num_beams`` / ``depth`` -- the reference's 70B engine; ``model``,
+    ``draft_model``, ``max_length``, sampling knobs ...): every rank of the default process group holds a contiguous
     slice of the target's layers (`split_layers`); rank 0 also holds the draft and gets the engine back, the other
     ranks serve forwards inside this call until rank 0 sends OP_STOP (`shutdown_pipeline`) and then return None.
     Launch with torch.distributed.run, one process per GPU; the process group must already be initialised."""
@@ -291,38 +358,51 @@ def build_pipelined_engine(device: str, dtype=torch.float16, seed: int = 0, **co
     from .models.config import KNOWN, LlamaCfg
     from .models.llama import Llama, pack_mask_bits
     from .speculation.static_speculation_engine import resolve_growmap_path
-    assert config.pop("engine", "static") == "static", "layer sharding is implemented for the static engine"
+    kind = config.pop("engine", "static")
+    assert kind in ("static", "dynamic"), kind
     rank, world = dist.get_rank(), dist.get_world_size()
     target, draft = config.pop("model"), config.pop("draft_model")
-    gm = config.pop("growmap", None)
-    if gm is None:
-        with open(resolve_growmap_path(config.pop("growmap_path"))) as f:
-            gm = _json.load(f)
-    else:
-        config.pop("growmap_path", None)
     max_length = config.get("max_length", 8192)
     cfg = KNOWN[target] if target in KNOWN else LlamaCfg.from_dir(target)
     lo, hi = split_layers(cfg.num_hidden_layers, world)[rank]
-    stage = Llama(target, max_length=max_length, device=device, dtype=dtype, seed=seed)
+    # `seed` is the engine's (sampling) seed, as in the single-GPU engines; synthetic weights are drawn from
+    # `weights_seed` (default 0 = what AutoModelLM.from_pretrained uses), so a sharded run sees the single-GPU model
+    stage = Llama(target, max_length=max_length, device=device, dtype=dtype, seed=config.pop("weights_seed", 0))
     stage.alloc(layer_range=(lo, hi))
-    T, depth_levels = gm["size"], len(gm["roots"])
+    if kind == "static":
+        gm = config.pop("growmap", None)
+        if gm is None:
+            with open(resolve_growmap_path(config.pop("growmap_path"))) as f:
+                gm = _json.load(f)
+        else:
+            config.pop("growmap_path", None)
+        T, max_path = gm["size"], len(gm["roots"])
+        depth = torch.tensor(gm["depth"], dtype=torch.int32, device=device)
+        mask_bits = pack_mask_bits((torch.tensor(gm["mask"]) == 1).to(device)).contiguous()
+    else:
+        W, Dp = config.get("width", 16), config.get("depth", 24)
+        T, max_path = W * Dp + 1, Dp + 1
+        depth = torch.tensor([0] + [i + 1 for i in range(Dp) for _ in range(W)], dtype=torch.int32, device=device)
+        mask_bits = torch.zeros(T, (T + 63) // 64, dtype=torch.int64, device=device)
     stage.reserve(max(stage.PREFILL_CHUNK, T), logit_rows=max(stage.CHUNK, T))
     host_staging = dist.get_backend() == "gloo"
-    comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.PREFILL_CHUNK, T), depth_levels,
+    comm = PipelineComm(rank, world, device, cfg.hidden_size, dtype, max(stage.PREFILL_CHUNK, T), max_path,
                         host_staging=host_staging)
     if rank != 0:
-        tables = dict(depth=torch.tensor(gm["depth"], dtype=torch.int32, device=device),
-                      mask_bits=pack_mask_bits((torch.tensor(gm["mask"]) == 1).to(device)).contiguous(),
-                      n_dev=torch.zeros(1, dtype=torch.int32, device=device),
+        tables = dict(depth=depth, mask_bits=mask_bits, n_dev=torch.zeros(1, dtype=torch.int32, device=device),
                       eos_dev=torch.tensor(list(cfg.eos_token_id), dtype=torch.int32, device=device),
-                      n_eos=len(cfg.eos_token_id), max_path=depth_levels, tree_size=T)
-        tables["mask_words"] = tables["mask_bits"].shape[1]
-        stage_worker(stage, comm, tables, use_graph=config.get("hip_graph", True))
+                      n_eos=len(cfg.eos_token_id), max_path=max_path, tree_size=T, dynamic=kind == "dynamic")
+        tables["mask_words"] = mask_bits.shape[1]
+        stage_worker(stage, comm, tables, mask_first_eos=kind == "dynamic", use_graph=config.get("hip_graph", True))
         return None
     for k in ("offload", "cuda_graph", "num_cache_layers"):      # single-GPU placement knobs of the reference
         config.pop(k, None)
-    eng = PipelinedStaticEngine(draft, target, dtype=dtype, device=device, growmap=gm, seed=seed,
-                                stage_model=stage, comm=comm, **config)
+    if kind == "static":
+        eng = PipelinedStaticEngine(draft, target, dtype=dtype, device=device, growmap=gm, seed=seed,
+                                    stage_model=stage, comm=comm, **config)
+    else:
+        eng = PipelinedDynamicEngine(draft, target, dtype=dtype, device=device, seed=seed, offload=False,
+                                     stage_model=stage, comm=comm, **config)
     eng.initialize()
     return eng
 
@@ -387,44 +467,56 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
     return out
 
 
+from .speculation.dynamic_speculation_engine import DynamicSpeculationEngine as _Dynamic  # noqa: E402
 from .speculation.static_speculation_engine import StaticSpeculationEngine as _Static  # noqa: E402
 
 
-class PipelinedStaticEngine(_Static):
-    """Static engine whose target is a PipelinedTarget (rank 0 of a layer-sharded group).  The draft tree replays as a
-    hipGraph, stage 0's share of the verify as another; hops, accept scan and the commit broadcast are eager."""
+class _PipelinedMixin:
+    """An engine whose target is a PipelinedTarget (rank 0 of a layer-sharded group).  The draft tree replays as a
+    hipGraph, stage 0's share of the verify as another; hops, accept scan and the commit broadcast are eager.  The last
+    stage samples (greedy or stochastic) and returns T token ids instead of [T, V] logits."""
+    DYNAMIC_MASK = False
 
-    def __init__(self, *a, stage_model=None, comm=None, **kw):
-        super().__init__(*a, **kw)
+    def _pp_init(self, stage_model, comm):
         self._stage_model, self._comm = stage_model, comm
         self._in_decode, self._pending = False, False
+        self._decode_knobs = None
 
     def initialize(self):
-        self._require_greedy()
         self._target_model = PipelinedTarget(self._stage_model, self._comm, self)
         super().initialize()
         self.graph_scope = "draft"                   # cross-rank hops cannot live inside the graph
 
-    def _require_greedy(self):
-        """The last stage returns arg-max token ids (T ints per verify) instead of [T, V] logits; sampling settings
-        that would need the logits on rank 0 are refused loudly rather than silently ignored."""
-        if not self._greedy():
-            raise ValueError("the layer-sharded engine verifies greedily: temperature >= 0.05 / repetition_penalty > 1.01 "
-                             "are not supported (BASELINE config 5 is greedy)")
+    def _knobs(self):
+        return (int(self._greedy()), _f2i(self.temperature), _f2i(self.topp), _f2i(self.repetition_penalty),
+                int(self.topk), int(self.seed))
 
     def update_generation_args(self, **generation_args):
         super().update_generation_args(**generation_args)
-        self._require_greedy()
+        if self._in_decode and self._knobs() != self._decode_knobs:
+            self._leave_decode()                     # the stages learn the new knobs with the next OP_DECODE plan
+
+    def manual_seed(self, seed: int):
+        super().manual_seed(seed)
+        if self._in_decode:
+            self._leave_decode()
 
     # ---- decode-mode bookkeeping: the commit of iteration i travels when rank 0 knows what follows it
+    def _commit_tokens(self):
+        """the tokens iteration i committed: positions n_old .. n_new (kept nodes + bonus), read after the accept scan"""
+        keep, n_new = int(self.res_host[0]), int(self.res_host[3])
+        return self.tokens[n_new - keep:n_new + 1] if keep > 0 else self.tokens[:0]
+
     def _flush_commit(self, cont):
         if self._pending:
-            self._comm.share_commit(self.res, self.path, cont=cont)
+            torch.cuda.current_stream().synchronize()            # res_host holds this iteration's accept result
+            self._comm.share_commit(self.res, self.path, cont=cont, newtok=self._commit_tokens())
             self._pending = False
 
     def _enter_decode(self):
         if not self._in_decode:
-            self._comm.plan(OP_DECODE)
+            self._decode_knobs = self._knobs()
+            self._comm.plan(OP_DECODE, *self._decode_knobs)
             self._in_decode = True
         else:
             self._flush_commit(cont=1)
@@ -437,6 +529,7 @@ class PipelinedStaticEngine(_Static):
                 # tokens, num_nodes unchanged, cont = 0 -- so reset() / a new prompt / shutdown work afterwards.
                 self.res.zero_()
                 self.res[3] = int(self.num_nodes)
+                self.res_host.copy_(self.res)
                 self._pending = True
             self._flush_commit(cont=0)
             self._in_decode = False
@@ -457,6 +550,8 @@ class PipelinedStaticEngine(_Static):
 
     def _verify_forward(self):
         self._enter_decode()
+        if self.DYNAMIC_MASK:
+            self._comm.bcast(self.mask_bits)                         # the stages' copy of this iteration's ancestor rows
         ids = self.target_model.verify_tree(self.tokens, self.n_dev, self.depth, self.tree_size, self.mask_bits,
                                             self.mask_words)
         self._remote_sampled = ids
@@ -467,7 +562,7 @@ class PipelinedStaticEngine(_Static):
         if self._comm.world > 1:
             self.sampled.copy_(self._remote_sampled)
         else:
-            _lib.call("umb_argmax_rows", self.sampled, self._stage_model.logits_buffer, self.tree_size, self.vocab_size)
+            self._sample()                                           # single-stage group: the logits are here
         _lib.call("umb_accept_scan", self.sampled, self.parents, self.tokens, self.n_dev, self.tree_size,
                   self.eos_dev, len(self.eos_tokens), self.res, self.path)
         self._pending = True                          # broadcast with the next iteration's `cont` (or on leaving)
@@ -477,3 +572,20 @@ class PipelinedStaticEngine(_Static):
 
     def verify(self):
         raise NotImplementedError("use step() on the pipelined engine")
+
+
+class PipelinedStaticEngine(_PipelinedMixin, _Static):
+    def __init__(self, *a, stage_model=None, comm=None, **kw):
+        super().__init__(*a, **kw)
+        self._pp_init(stage_model, comm)
+
+
+class PipelinedDynamicEngine(_PipelinedMixin, _Dynamic):
+    """The reference's 70B engine (dynamic_speculation_engine.py:215-327: beam-grown tree, stochastic verification)
+    over a layer-sharded target: the beam expansion stays on rank 0 with the draft; each iteration's ancestor-mask rows
+    are broadcast to the stages ahead of the activations."""
+    DYNAMIC_MASK = True
+
+    def __init__(self, *a, stage_model=None, comm=None, **kw):
+        super().__init__(*a, **kw)
+        self._pp_init(stage_model, comm)

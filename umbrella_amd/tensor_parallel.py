@@ -3,20 +3,25 @@
 Layer sharding (parallel.py) adds capacity; the only route to a faster single request beyond one GPU's HBM is to
 split every layer: rank r of P holds
     q / k / v rows of its Hq/P query and Hkv/P key-value heads   (column split: no communication)
-    the o_proj columns of those heads                            (row split: fp32 partial [T, H] -> all-reduce)
+    the o_proj columns of those heads                            (row split: fp32 partial sums -> all-reduce)
     gate / up rows [r I/P, (r+1) I/P)                            (column split)
-    the down_proj columns of that slice                          (row split: fp32 partial [T, H] -> all-reduce)
-    lm_head rows [r V/P, (r+1) V/P)                              (column split: local arg-max, (value, index) pairs gathered)
-with norms, the residual stream and the embedding replicated.  Two all-reduces of a [T, H] fp32 tile per layer
-(426 KB at T = 13, H = 8192) over RCCL -- xGMI is point to point, so at these sizes the collective is latency
-bound and the right degree is small (2-4): 160 all-reduces per 70B verify at ~10-20 us each is the price of
-streaming 1/P of the weights.  Unmeasured here (one GPU per box); correct by construction:
-  * the sharding helpers are pure torch and are pinned on CPU against the unsharded oracle (gloo, world 2);
-  * on the GPU the P shards run in ONE process with an in-process sum standing in for the all-reduce and must
-    reproduce the unsharded model up to fp32 summation order (tests/test_tensor_parallel.py).
-SPMD: every rank runs the same engine (the 1B draft is replicated -- it is small and deterministic, so all ranks
-grow the same tree without talking), and the sharded target forward meets at the collectives.  No control channel.
-Kernels: the low-latency GEMM family (csrc/lowlat.hip) on the local shard; T <= 64 rows per forward.
+    the down_proj columns of that slice                          (row split: fp32 partial sums -> all-reduce)
+    lm_head rows [r V/P, (r+1) V/P)                              (column split: logits all-gathered along the vocabulary)
+with norms, the residual stream and the embedding replicated.
+
+The layer chain is the SAME native one a single GPU runs (csrc/model.hip, the 8-launch schedule, any T: tree verify,
+wide dynamic trees, 1024-token prompt chunks): `umb_model_forward_tp` calls back for an all-reduce behind the two
+row-split GEMMs of every layer, and this module answers with RCCL (`torch.distributed` "nccl") on the launch stream --
+so a whole iteration, collectives included, still replays as ONE hipGraph per rank; at world 1 no collective is issued
+and the path is the plain engine's.  xGMI is point to point: a [T, H] fp32 tile (426 KB at T = 13, H = 8192; its 4
+split-K slabs travel together, 1.7 MB) is latency bound, 160 of them per 70B verify.
+The engines are the ordinary ones (static or dynamic, greedy or stochastic): the target they see is
+`TensorParallelLlama`, whose `logits_buffer` holds the all-gathered [T, V] logits, so sampling, accept scan and KV
+compaction are unchanged; every rank runs the same engine (SPMD) with the small draft replicated -- deterministic
+kernels and a shared seed make all ranks grow and accept the same tree without a control channel.
+Tests: sharding algebra on CPU (gloo, world 2); two processes sharing one GPU over host-staged gloo reproduce the
+single-process engine's tokens (tests/test_tensor_parallel.py); RCCL itself is exercised at world 1 on the test box,
+including its capture into the iteration graph.
 """
 from __future__ import annotations
 
@@ -43,6 +48,7 @@ def local_config(cfg: LlamaCfg, world: int) -> LlamaCfg:
     c.num_attention_heads //= world
     c.num_key_value_heads //= world
     c.intermediate_size //= world
+    c.embed_rows = cfg.vocab_size               # the embedding table stays whole (replicated); only the head is split
     c.vocab_size //= world
     c.tie_word_embeddings = False
     return c
@@ -128,263 +134,193 @@ class LazySyntheticShard:
         return shard_tensor(name, t, self.cfg, self.rank, self.world).contiguous()
 
 
-# ------------------------------------------------------------------ communicators
-class DistComm:
-    """one shard per process; RCCL ("nccl") on GPUs, gloo on CPU"""
+# ------------------------------------------------------------------ communicator
+class TPComm:
+    """The tensor-parallel group: RCCL ("nccl") with one GPU per rank; gloo (host staged) where ranks share a GPU (tests)
+    or live on the CPU.  Collectives are issued on the current stream, so under hipGraph capture they become graph nodes."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.live = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.live else 0
+        self.world = dist.get_world_size(group) if self.live else 1
+        self.backend = dist.get_backend(group) if self.live else "none"
+        self.staged = self.backend == "gloo"
 
-    def all_reduce(self, tensors):
-        self.dist.all_reduce(tensors[0], group=self.group)
+    def all_reduce(self, t: torch.Tensor):
+        if not self.live:
+            return
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
 
-    def gather_max(self, vals, idxs, vocab_per_rank):
-        """per-row (max value, global index) over the ranks' vocabulary slices; ties -> lowest index"""
-        v, i = vals[0], idxs[0]
-        pack = torch.stack([v, (i + self.rank * vocab_per_rank).float()], dim=-1).contiguous()
-        allp = [torch.empty_like(pack) for _ in range(self.world)]
-        self.dist.all_gather(allp, pack, group=self.group)
-        return [_pick(allp)]
-
-
-class LocalComm:
-    """all P shards in this process (single-GPU tests): the all-reduce is a sum over the shard list, in rank order --
-    the order a ring all-reduce of a tile this small would be reduced in is not specified, so parity is to fp32 order"""
-
-    def __init__(self, world):
-        self.rank, self.world = 0, world
-
-    def all_reduce(self, tensors):
-        total = tensors[0].clone()
-        for t in tensors[1:]:
-            total += t
-        for t in tensors:
-            t.copy_(total)
-
-    def gather_max(self, vals, idxs, vocab_per_rank):
-        allp = [torch.stack([v, (i + r * vocab_per_rank).float()], dim=-1) for r, (v, i) in enumerate(zip(vals, idxs))]
-        return [_pick(allp)] * len(vals)
-
-
-def _pick(allp):
-    vals = torch.stack([p[:, 0] for p in allp])            # [P, T]
-    idx = torch.stack([p[:, 1] for p in allp])
-    # ties -> lowest global vocabulary index, by construction (torch.argmax does not promise which maximal entry it
-    # returns): the minimum index among the entries equal to the column maximum; a NaN shard maximum counts as -inf on
-    # every rank alike, so all ranks agree on the token.
-    vals = torch.nan_to_num(vals, nan=-float("inf"))
-    mx = vals.max(dim=0, keepdim=True).values
-    cand = torch.where(vals == mx, idx, torch.full_like(idx, float("inf")))
-    return cand.min(dim=0).values.to(torch.int32)
+    def all_gather_columns(self, local: torch.Tensor, full: torch.Tensor, scratch: torch.Tensor | None = None):
+        """local [rows, Vl] of every rank -> full [rows, world * Vl] (rank r's columns at [r Vl, (r + 1) Vl))"""
+        rows, Vl = local.shape
+        if self.world == 1:
+            full.copy_(local)
+            return
+        if self.staged and local.is_cuda:
+            h = local.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(parts, h, group=self.group)
+            full.copy_(torch.cat(parts, dim=1))
+            return
+        buf = scratch[:self.world * rows * Vl].view(self.world, rows, Vl) if scratch is not None else \
+            torch.empty(self.world, rows, Vl, dtype=local.dtype, device=local.device)
+        self.dist.all_gather_into_tensor(buf.view(-1), local.reshape(-1), group=self.group)
+        full.view(rows, self.world, Vl).copy_(buf.transpose(0, 1))
 
 
 # ------------------------------------------------------------------ the sharded target
 class TensorParallelLlama:
-    """P shards of one Llama target.  ``shards`` are `Llama` objects built on `local_config` / `shard_state_dict`
-    (one per process with DistComm, all P with LocalComm); the embedding table is replicated."""
+    """This rank's shard of one Llama target behind the model-runtime face the engines use.  `shard` is a `Llama` built on
+    `local_config` (1/P of the heads, the MLP width and the vocabulary; whole embedding table) whose forward runs
+    `umb_model_forward_tp`; this wrapper owns the all-reduce hook and the vocabulary all-gather of the logits."""
 
-    CHUNK = 64
-    PREFILL_CHUNK = 64
-
-    def __init__(self, cfg: LlamaCfg, shards, embed: torch.Tensor, comm):
-        self.config, self.shards, self.comm, self.embed = cfg, shards, comm, embed.contiguous()
-        self.world = comm.world
-        m = shards[0]
-        self.device, self.dtype, self.max_length, self.eos_tokens = m.device, m.dtype, m.max_length, list(cfg.eos_token_id)
-        self.num_layers = m.num_layers
-        self.kv_cache = _ShardedKV([s.kv_cache for s in shards])
-        self.sampled_ids = torch.zeros(1024, dtype=torch.int32, device=self.device)
+    def __init__(self, cfg: LlamaCfg, shard, comm: TPComm, force_hook: bool = False):
+        import ctypes as C
+        self.config, self.m, self.comm = cfg, shard, comm
+        self.world, self.rank = comm.world, comm.rank
+        self.device, self.dtype, self.max_length = shard.device, shard.dtype, shard.max_length
+        self.eos_tokens = list(cfg.eos_token_id)
+        self.num_layers, self.kv_cache = shard.num_layers, shard.kv_cache
+        self.CHUNK, self.PREFILL_CHUNK = shard.CHUNK, shard.PREFILL_CHUNK
         self._off = None
-        T = 64
-        self._part = [torch.zeros(T, cfg.hidden_size, dtype=torch.float32, device=self.device) for _ in shards]
-        self._xfm = [torch.zeros(T * cfg.hidden_size, dtype=self.dtype, device=self.device) for _ in shards]
-        self._topv = [torch.zeros(T, dtype=torch.float32, device=self.device) for _ in shards]
-        self._topi = [torch.zeros(T, dtype=torch.int32, device=self.device) for _ in shards]
+        self.sched = "split"
+        self._err = None
+
+        def hook(ctx, buf, count, stream):
+            try:
+                part = self.m._bufs["partial"]
+                assert buf == part.data_ptr() and count <= part.numel(), "all-reduce outside the split-K partial buffer"
+                self.comm.all_reduce(part[:count])
+                return 0
+            except Exception as e:                      # never unwind through the C frame
+                self._err = e
+                return 1
+        self._hook = _lib.ALLREDUCE_FN(hook)            # keep the trampoline alive as long as the model
+        tp = _lib.UmbTP()
+        # force_hook (tests): issue the collectives even in a 1-rank group (RCCL all-reduce over one rank = identity)
+        tp.rank, tp.world = self.rank, (max(self.world, 2) if force_hook else self.world)
+        tp.allreduce, tp.ctx = self._hook, None
+        shard._tp = tp
+        self._alloc_gather()
 
     @classmethod
-    def build(cls, cfg: LlamaCfg, state_dict: dict, world: int, comm, max_length, device, dtype, ranks=None, name="tp"):
+    def build(cls, cfg: LlamaCfg, source, comm: TPComm, max_length, device, dtype, name="tp", seed=0, force_hook=False):
+        """source: a full state dict (sliced here with shard_state_dict), or any mapping name -> THIS rank's slice
+        (LazySyntheticShard; a checkpoint reader wrapped with shard_tensor)."""
         from .models.llama import Llama
-        lc = local_config(cfg, world)
-        shards = []
-        for r in (ranks if ranks is not None else [comm.rank]):
-            if isinstance(state_dict, dict):
-                sd = dict(shard_state_dict(state_dict, cfg, r, world))
-            else:                                           # lazy per-rank mapping (LazySyntheticShard): already sliced
-                assert ranks is None or len(ranks) == 1
-                sd = state_dict
-            m = Llama(f"{name}-shard{r}", max_length=max_length, device=device, dtype=dtype,
-                      state_dict=_EmbedPlaceholder(sd, lc.vocab_size), config=lc)
-            m.alloc()
-            shards.append(m)
-        embed = state_dict["model.embed_tokens.weight"].to(device=device, dtype=dtype)
-        return cls(cfg, shards, embed, comm)
+        lc = local_config(cfg, comm.world)
+        sd = dict(shard_state_dict(source, cfg, comm.rank, comm.world)) if isinstance(source, dict) else source
+        m = Llama(f"{name}-tp{comm.rank}of{comm.world}", max_length=max_length, device=device, dtype=dtype, state_dict=sd,
+                  config=lc, seed=seed, sched="split")
+        m.alloc()
+        return cls(cfg, m, comm, force_hook=force_hook)
+
+    # ---- buffers
+    def _alloc_gather(self):
+        rows = self.m.logit_rows
+        V, Vl = self.config.vocab_size, self.m.config.vocab_size
+        assert V == Vl * self.world
+        self._full = torch.empty(rows, V, dtype=torch.float32, device=self.device)
+        self._scratch = torch.empty(self.world * rows * Vl, dtype=torch.float32, device=self.device) \
+            if (self.world > 1 and not self.comm.staged) else None
 
     def reserve(self, tokens, logit_rows=None):
-        pass                                                # forwards run in <= 64-row pieces on the shards' default workspace
+        before = (self.m.ws_tokens, self.m.logit_rows)
+        self.m.reserve(tokens, logit_rows)
+        if (self.m.ws_tokens, self.m.logit_rows) != before:
+            self._alloc_gather()
 
-    def clear(self):
-        for s in self.shards:
-            s.clear()
+    @property
+    def logits_buffer(self) -> torch.Tensor:
+        return self._full
 
-    def weight_bytes(self):
-        return self.shards[0].weight_bytes()
+    @property
+    def ws_tokens(self):
+        return self.m.ws_tokens
 
-    # ---- one <= 64-row forward; returns nothing: arg-max ids of rows [head_from, T) land in self.sampled_ids[:T - head_from]
-    def _forward(self, step_args, T, head_from, mask_first_eos=None):
-        call, dt = _lib.call, _lib.dtype_code(self.dtype)
-        cfg, lc = self.config, self.shards[0].config
-        H, tt = cfg.hidden_size, _lib.load().umb_ll_token_tiles(T)
-        for sh, part, xfm in zip(self.shards, self._part, self._xfm):
-            b = sh._bufs
-            tok, pos, slot, prefix, tokens_all, n_ptr, off, depth = step_args
-            # embedding gather + index resolution (replicated); hw / ssq outputs of the kernel are not used here
-            call("umb_embed_ll", b["h"], self.embed, H, cfg.vocab_size, sh.max_length, T, tok, pos, slot, prefix, tokens_all,
-                 n_ptr, off, depth, b["pos"], b["slot"], b["prefix"], b["hw"], sh.norms[0][0], b["ssq"], sh.ssq_stride, dt)
-            call("umb_rmsnorm", b["xn"], b["h"], sh.norms[0][0], cfg.rms_norm_eps, T, H, dt)
-        for l in range(self.num_layers):
-            last = l + 1 == self.num_layers
-            for sh, part, xfm in zip(self.shards, self._part, self._xfm):
-                b, lins = sh._bufs, sh.layers[l]
-                kc, vt = sh.kv_cache.k[l], sh.kv_cache.vt[l]
-                call("umb_to_fm", xfm, b["xn"], T, H, dt)
-                fq = _lib.UmbGemmLL()
-                fq.pos, fq.slot, fq.cosT, fq.sinT = b["pos"].data_ptr(), b["slot"].data_ptr(), sh.cos_cache.data_ptr(), sh.sin_cache.data_ptr()
-                fq.q_out, fq.k_cache, fq.vt_cache = b["q"].data_ptr(), kc.data_ptr(), vt.data_ptr()
-                fq.bias = sh.qkv_biases[l].data_ptr() if sh.qkv_biases[l] is not None else None
-                fq.Hq, fq.Hkv, fq.D, fq.Lmax = lc.num_attention_heads, lc.num_key_value_heads, lc.head_dim, sh.max_length
-                q = lins["qkv"]
-                call("umb_gemm_ll", None, xfm, q.w, q.meta, T, q.N, q.K, q.awq, 3, fq, dt)
-                call("umb_tree_attn2", b["attn"], b["q"], kc, vt, b["po"], b["ml"], b["prefix"], self._mask[0], self._mask[1],
-                     self._mask[2], T, lc.num_attention_heads, lc.num_key_value_heads, lc.head_dim, sh.max_length,
-                     sh.attn_chunk, sh.attn_splits, 1.0 / (lc.head_dim ** 0.5), sh._attn_counters, tt, dt)
-                o = lins["o"]
-                call("umb_gemm_ll", part, b["attn"], o.w, o.meta, T, o.N, o.K, o.awq, 0, _lib.UmbGemmLL(), dt)
-            self.comm.all_reduce([p[:T] for p in self._part])
-            for sh, part, xfm in zip(self.shards, self._part, self._xfm):
-                b, lins = sh._bufs, sh.layers[l]
-                call("umb_reduce_residual_norm", part, 1, T, H, b["h"], b["h"], b["xn"], sh.norms[l][1], cfg.rms_norm_eps, dt)
-                call("umb_to_fm", xfm, b["xn"], T, H, dt)
-                gu, dn = lins["gu"], lins["down"]
-                call("umb_gemm_ll", b["act"], xfm, gu.w, gu.meta, T, gu.N, gu.K, gu.awq, 2, _lib.UmbGemmLL(), dt)
-                call("umb_gemm_ll", part, b["act"], dn.w, dn.meta, T, dn.N, dn.K, dn.awq, 0, _lib.UmbGemmLL(), dt)
-            self.comm.all_reduce([p[:T] for p in self._part])
-            for sh, part in zip(self.shards, self._part):
-                b = sh._bufs
-                nxt = sh.norm_weight if last else sh.norms[l + 1][0]
-                call("umb_reduce_residual_norm", part, 1, T, H, b["h"], b["h"], b["xn"], nxt, cfg.rms_norm_eps, dt)
-        rows = T - head_from
-        if rows <= 0:
-            return
-        Vl = lc.vocab_size
-        for r, (sh, xfm, tv, ti) in enumerate(zip(self.shards, self._xfm, self._topv, self._topi)):
-            b = sh._bufs
-            call("umb_to_fm", xfm, b["xn"], T, H, dt)
-            fh = _lib.UmbGemmLL()
-            fh.row_from, fh.round_out = head_from, 1
-            hd = sh.lm_head
-            call("umb_gemm_ll", b["logits"], xfm, hd.w, hd.meta, T, hd.N, hd.K, hd.awq, 0, fh, dt)
-            if mask_first_eos:                             # dynamic engine: EOS ids to -inf on the last row before the arg-max
-                base = (self.comm.rank if len(self.shards) == 1 else r) * Vl
-                loc = [e - base for e in mask_first_eos if base <= e < base + Vl]
-                if loc:
-                    b["logits"][rows - 1, loc] = -float("inf")
-            call("umb_topk_rows", ti, tv, b["logits"], rows, Vl, 1, None, None, None, None)
-        ids = self.comm.gather_max([v[:rows] for v in self._topv], [i[:rows] for i in self._topi], Vl)
-        self.sampled_ids[:rows] = ids[0]
+    @property
+    def logit_rows(self):
+        return self.m.logit_rows
 
-    # ---- the model-runtime face the engines use
+    def _gather(self, rows):
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+        if rows > 0:
+            self.comm.all_gather_columns(self.m._bufs["logits"][:rows], self._full[:rows], self._scratch)
+
+    # ---- the model-runtime face
     def forward_tree(self, tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=0, **kw):
-        assert T <= 64, "tensor-parallel verify handles trees of <= 64 nodes (low-latency kernels)"
-        self._mask = (mask_bits.data_ptr() + tree_off * mask_words * 8, mask_words, tree_off + T)
-        self._keep = (mask_bits,)
-        self._forward((None, None, None, None, tokens_all, n_ptr, tree_off, depth), T, head_from)
+        self.m.forward_tree(tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=head_from, **kw)
+        self._gather(T - head_from)
 
+    def forward_explicit(self, tokens, positions, slots, prefix_len, mask_bits=None, mask_words=0, n_mask_keys=None,
+                         head_from=0, **kw):
+        self.m.forward_explicit(tokens, positions, slots, prefix_len, mask_bits=mask_bits, mask_words=mask_words,
+                                n_mask_keys=n_mask_keys, head_from=head_from, **kw)
+        self._gather(tokens.shape[0] - head_from)
+
+    @torch.inference_mode()
     def prefill_tokens(self, ids, start, want_logits=True):
-        """causal forward in <= 64-row pieces; returns int32[1] = arg-max id of the last row when asked"""
+        """causal forward over ids placed at slots / positions start.. (Llama.prefill_tokens, sharded): the fp32 logits
+        row of the last token, all V columns, when asked"""
         P = ids.shape[0]
-        dev = self.device
         out = None
-        for lo in range(0, P, self.CHUNK):
-            hi = min(P, lo + self.CHUNK)
+        chunk = max(self.CHUNK, min(self.PREFILL_CHUNK, self.m.ws_tokens))
+        for lo in range(0, P, chunk):
+            hi = min(P, lo + chunk)
             T = hi - lo
-            pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=dev)
-            pre = torch.tensor([start + lo], dtype=torch.int32, device=dev)
+            pos = torch.arange(start + lo, start + hi, dtype=torch.int32, device=self.device)
+            pre = torch.tensor([start + lo], dtype=torch.int32, device=self.device)
             last = hi == P and want_logits
-            self._mask = (None, 0, T)
-            self._keep = (pos, pre)
-            self._forward((ids[lo:hi].contiguous(), pos, pos, pre, None, None, 0, None), T, T - 1 if last else T,
-                          mask_first_eos=self._first_eos if last else None)
+            self.forward_explicit(ids[lo:hi].contiguous(), pos, pos, pre, head_from=(T - 1 if last else T))
             if last:
-                out = self.sampled_ids[:1].clone()
+                out = self._full[0]
         self.kv_cache.kv_offset = start + P
         return out
 
-    _first_eos = None
-
-
-class _EmbedPlaceholder:
-    """what a shard's `Llama` sees: its slice of everything, and a V/P-row stand-in for the embedding table (the real,
-    replicated table lives in TensorParallelLlama.embed; the shard never embeds)"""
-
-    def __init__(self, sd, rows):
-        self.sd, self.rows = sd, rows
-
-    def __getitem__(self, name):
-        t = self.sd[name]
-        return t[:self.rows] if name == "model.embed_tokens.weight" else t
-
-
-class _ShardedKV:
-    def __init__(self, caches):
-        self.caches = caches
-        self.kv_offset = 0
-
-    def compact(self, result, path, max_path):
-        for c in self.caches:
-            c.compact(result, path, max_path)
+    def gather_kv_incremental(self, indices, offset):
+        self.kv_cache.gather_kv_incremental(indices, offset)
 
     def clear(self):
-        for c in self.caches:
-            c.clear()
-        self.kv_offset = 0
+        self.m.clear()
+
+    def weight_bytes(self):
+        return self.m.weight_bytes()
 
 
-# ------------------------------------------------------------------ engine
-from .speculation.static_speculation_engine import StaticSpeculationEngine as _Static  # noqa: E402
-
-
-class TensorParallelStaticEngine(_Static):
-    """Static (Sequoia) engine over a TensorParallelLlama target.  SPMD: every rank constructs and drives the same
-    engine; the draft tree is a hipGraph, the sharded verify is launched eagerly (collectives in between)."""
-
-    def __init__(self, *a, tp_target=None, **kw):
-        super().__init__(*a, target_model_obj=tp_target, **kw)
-
-    def initialize(self):
-        if not self._greedy():
-            raise ValueError("the tensor-parallel engine verifies greedily (the logits stay sharded over the ranks)")
-        super().initialize()
-        self.graph_scope = "draft"
-
-    def update_generation_args(self, **generation_args):
-        super().update_generation_args(**generation_args)
-        if not self._greedy():
-            raise ValueError("the tensor-parallel engine verifies greedily")
-
-    def _feed(self, lo, hi):
-        ids = self.tokens[lo:hi]
-        dlo = lo - 1 if (self.lookback and lo > 0) else lo
-        self.draft_model.prefill_tokens(self.tokens[dlo:hi], dlo, want_logits=False)
-        first = self.target_model.prefill_tokens(ids, lo, want_logits=True)
-        self.tokens[hi:hi + 1] = first
-        self.num_nodes = hi
-        self.n_dev.fill_(hi)
-        self.last_bonus = None
-
-    def _sample(self, dbg=None):
-        self.sampled.copy_(self.target_model.sampled_ids[:self.tree_size])
+def build_tp_engine(device: str, dtype=torch.float16, seed: int = 0, source=None, comm: TPComm | None = None,
+                    force_hook: bool = False, **config):
+    """Reference-style engine config (``engine``, ``model``, ``draft_model``, ``growmap`` | ``growmap_path`` | width /
+    num_beams / depth, sampling knobs ...) -> the ordinary static / dynamic engine over a tensor-parallel target.
+    SPMD: every rank of the group calls this and drives its engine identically.  `source`: name -> tensor mapping of
+    the target's checkpoint (default: seeded synthetic tensors of the configured shapes, UMBRELLA_SYNTHETIC=1)."""
+    from .models.auto_model import AutoModelLM
+    from .models.config import KNOWN
+    from .speculation.auto_engine import AutoEngine
+    comm = comm or TPComm()
+    target = config["model"]
+    cfg = KNOWN[target] if target in KNOWN else LlamaCfg.from_dir(target)
+    max_length = config.get("max_length", 8192)
+    if source is None:
+        source = LazySyntheticShard(cfg, comm.rank, comm.world, device, dtype, seed=seed)
+    tp = TensorParallelLlama.build(cfg, source, comm, max_length, device, dtype, name=target, seed=seed, force_hook=force_hook)
+    for k in ("offload", "num_cache_layers"):                    # single-GPU placement knobs of the reference
+        config.pop(k, None)
+    if config.get("engine", "dynamic") == "dynamic":
+        config["offload"] = False
+    if comm.staged:
+        config["hip_graph"] = False                              # a host-staged collective cannot live in a hipGraph
+    eng = AutoEngine.from_config(device, dtype=dtype, seed=seed, target_model_obj=tp, **config)
+    return eng
 
 
 def tp_measure(args, wl, dtype, device, rank, world):
@@ -395,18 +331,12 @@ def tp_measure(args, wl, dtype, device, rank, world):
     import torch.distributed as dist
 
     import __graft_entry__ as ge
-    from .models.auto_model import AutoModelLM
     from .models.config import KNOWN
     from .sequoia_utils import generate_sequoia_tree
     ge.build()
     cfg = KNOWN[wl["target"]]
-    comm = DistComm()
-    tp = TensorParallelLlama.build(cfg, LazySyntheticShard(cfg, rank, world, device, dtype, seed=args.seed), world, comm,
-                                   args.max_length, device, dtype, name=wl["target"])
-    draft = AutoModelLM.from_pretrained(wl["draft"], max_length=args.max_length, device=device, dtype=dtype, cuda_graph=True)
-    draft.alloc(exit_layer=16)
-    eng = TensorParallelStaticEngine(wl["draft"], wl["target"], dtype=dtype, device=device, growmap=generate_sequoia_tree(3, 4),
-                                     max_length=args.max_length, draft_model_obj=draft, tp_target=tp, seed=args.seed)
+    eng = build_tp_engine(device, dtype=dtype, seed=args.seed, engine="static", model=wl["target"], draft_model=wl["draft"],
+                          growmap=generate_sequoia_tree(3, 4), max_length=args.max_length, exit_layer=16)
     eng.initialize()
     g = torch.Generator().manual_seed(1234)
     prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)
@@ -428,9 +358,10 @@ def tp_measure(args, wl, dtype, device, rank, world):
     return {"ms_per_step": round(dt / args.steps * 1e3, 4), "tokens_per_s_raw_draft": round(tokens / dt, 2),
             "accept_len_raw_draft": round(tokens / args.steps, 3), "n_ranks_rccl": world,
             "backend": dist.get_backend() if dist.is_initialized() else "none",
-            "allreduces_per_verify": 2 * cfg.num_hidden_layers, "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4,
-            "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 tile per "
-                           "layer; draft replicated", "tree": "3x4", "scaling": "strong"}
+            "allreduces_per_verify": 2 * cfg.num_hidden_layers if world > 1 else 0,
+            "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4, "iteration_in_one_hipgraph": bool(eng.use_graph and eng.graph_scope == "iteration"),
+            "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 partial "
+                           "sums per layer inside the native layer chain; draft replicated", "tree": "3x4", "scaling": "strong"}
 
 
 def run_tp_bench(args, wl, dtype, device, rank, world):
