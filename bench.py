@@ -211,7 +211,7 @@ def kernel_roofline(eng, reps=40):
             # low-latency schedule, large-N gate/up: LDS-shared kernel, FM in / FM out, 1/rms from the sums of squares
             fs = _lib.UmbGemmFused()
             fs.ssq_in, fs.ssq_groups, fs.pad0, fs.ssq_dim, fs.eps, fs.pad1 = ssq.data_ptr(), K // 32, ssq.shape[1], float(K), 1e-5, 3
-            launch = lambda ln: _lib.call("umb_gemm_fused", act, xfm, K, ln.w, ln.meta, T, N, K, ln.awq, 1, ln.R, 2, fs, dt)
+            launch = lambda ln: _lib.call("umb_gemm_fused", act, xfm, K, ln.w, ln.meta, T, N, K, ln.awq, 1, ln.Rtb, 2, fs, dt)
             info = {"family": "split-K kernel (S=1, FM buffers)", "R": lin0.R, "S": 1}
         elif ll:
             R, WN, WK, NW = ll_plan(N, K, bool(lin0.awq))
@@ -230,12 +230,14 @@ def kernel_roofline(eng, reps=40):
             S = lin0.S
             if key in ("o", "down"):                    # model.hip eff_s(): split count of the row-reduced linears
                 cap = max(K // 1792, 4)
-                if S > cap and (N // (64 * max(lin0.R, 1))) * cap >= 256:
+                if lin0.S_row > 0:
+                    S = lin0.S_row
+                elif S > cap and (N // (64 * max(lin0.R, 1))) * cap >= 256:
                     S = cap
             epi = 2 if key == "gu" else 0
             out = act if key == "gu" else part
-            launch = lambda ln: _lib.call("umb_gemm", out, x, x.stride(0), ln.w, ln.meta, T, N, K, ln.awq, S, ln.R, epi, dt)
-            info = {"family": "split-K", "R": lin0.R, "S": S}
+            launch = lambda ln: _lib.call("umb_gemm", out, x, x.stride(0), ln.w, ln.meta, T, N, K, ln.awq, S, ln.Rtb, epi, dt)
+            info = {"family": "split-K", "R": lin0.R, "S": S, "tiles_per_block": lin0.tb or 4 * lin0.R}
         for i in range(4):
             launch(m.layers[i % L][key])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -47,6 +47,10 @@ int umb_awq_repack(void* outw, void* meta, const void* qweight, const void* qzer
 /* ------------------------------------------------------------------ linear layers */
 /* split plan for a [N][K] linear: depends on (N, K, format) only, never on T. */
 void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, int* S_out);
+/* the full plan: R n-tiles per wave, S K-splits, tb n-tiles per 4-wave block (4 R, or one less where that makes
+ * nblk * S whole rounds of 2 blocks per CU -- a launch is as fast as its busiest CU) and S_row = the split count to use
+ * when the partials go to the one-block-per-row reduce kernel (0: the runtime's rule).  Shape-only. */
+void umb_gemm_plan2(int N, int K, int awq, int force_s1, int* R_out, int* S_out, int* tb_out, int* S_row_out);
 /* split count the model runtime uses for a T-token forward of that linear: the plan's S for T <= 64 (so a token's
  * result does not depend on its batch mates there); for wider forwards (tree verify, prompt chunks) the S <= plan
  * that fills the 2 x 256 block slots of the register-resident verify kernel about once. */
@@ -56,7 +60,8 @@ int umb_gemm_wide_split(int T, int N, int S_plan);
  * AwqLinear.apply -> awq_ext.gemm_forward_cuda / dequantize_weights_cuda
  * (umbrella/quantization/awq_utils.py:63-86).  epi: 0 raw fp32 partials; 1 round results to `dtype`
  * (what F.linear(...).float() yields for the lm_head, llama.py:133); 2 fused SiLU(gate)*up
- * (llama.py:107-110): needs S == 1 and interleaved rows, `out` is then 16-bit act[T][N/2]. */
+ * (llama.py:107-110): needs S == 1 and interleaved rows, `out` is then 16-bit act[T][N/2].
+ * R: low byte = n-tiles per wave; bits 8..15 = n-tiles per block `tb` of the plan (0: 4 R). */
 int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
              int awq, int S, int R, int epi, int dtype, umb_stream_t stream);
 
@@ -235,6 +240,7 @@ typedef struct UmbLinear {
   const void* w;        /* packed tiles */
   const void* meta;     /* AWQ scale/zero tiles or NULL */
   int32_t N, K, awq, R, S;
+  int32_t tb, S_row;    /* umb_gemm_plan2: n-tiles per block (0: 4 R); split count under the row reduce (0: rule) */
   int32_t pad_;
 } UmbLinear;
 

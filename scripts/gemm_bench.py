@@ -36,7 +36,7 @@ for model in sys.argv[1:] or ["70b", "1b"]:
 
         def launch(i):
             l = lins[i % ncopy]
-            _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, l.awq, l.S, l.R, epi, _lib.dtype_code(dtype))
+            _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, l.awq, l.S, l.Rtb, epi, _lib.dtype_code(dtype))
         for i in range(3):
             launch(i)
         reps = 30

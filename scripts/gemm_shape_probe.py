@@ -20,7 +20,7 @@ for N in [int(a) for a in sys.argv[1:]] or [49152, 57344, 65536]:
     l0 = lins[0]
     def launch(i):
         l = lins[i % len(lins)]
-        _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, 1, l.S, l.R, 2, _lib.dtype_code(dtype))
+        _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, 1, l.S, l.Rtb, 2, _lib.dtype_code(dtype))
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         launch(0); launch(1); torch.cuda.synchronize()

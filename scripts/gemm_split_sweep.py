@@ -36,7 +36,7 @@ for name, N, K, awq in SHAPES:
             break
         def launch(i):
             l = lins[i % len(lins)]
-            _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, l.awq, S, l.R, 0, _lib.dtype_code(dtype))
+            _lib.call("umb_gemm", out, x, K, l.w, l.meta, T, N, K, l.awq, S, l.Rtb, 0, _lib.dtype_code(dtype))
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             launch(0); torch.cuda.synchronize()

@@ -68,10 +68,12 @@ def bench_shapes(model):
         S_eff = ln.S
         if name in ("o", "down") and T <= 64:           # what model.hip's eff_s() does for the row-reduced GEMMs
             cap = max(K // 1792, 4)
-            if ln.S > cap and (N // (64 * ln.R)) * cap >= 256:
+            if ln.S_row > 0:
+                S_eff = ln.S_row
+            elif ln.S > cap and (N // (64 * ln.R)) * cap >= 256:
                 S_eff = cap
 
-        R_old = int(os.environ.get("R_OLD", ln.R))
+        R_old = int(os.environ.get("R_OLD", ln.R)) | (int(os.environ.get("TB_OLD", ln.tb)) << 8)
         if os.environ.get("S_OLD") and epi_old == 0:
             S_eff = int(os.environ["S_OLD"])
             part = torch.empty(max(S_eff * T * N, 1), dtype=torch.float32, device=dev)
@@ -182,7 +184,7 @@ def bench_graphscan():
         def gemms():
             for i in range(nl):
                 l = lins[i % ncopy]
-                _lib.call("umb_gemm", act, x, K, l.w, l.meta, T, N, K, l.awq, 1, l.R, 2, dt)
+                _lib.call("umb_gemm", act, x, K, l.w, l.meta, T, N, K, l.awq, 1, l.Rtb, 2, dt)
 
         def reads():
             for i in range(nl):

@@ -33,9 +33,9 @@ def test_struct_layouts_match_header(lib):
     """ctypes mirrors must have the C struct sizes (LP64)."""
     import ctypes as C
     from umbrella_amd import _lib
-    assert C.sizeof(_lib.UmbLinear) == 40
-    assert C.sizeof(_lib.UmbLayer) == 4 * 40 + 24
-    assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 40 + 6 * 8
+    assert C.sizeof(_lib.UmbLinear) == 48
+    assert C.sizeof(_lib.UmbLayer) == 4 * 48 + 24
+    assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 48 + 6 * 8
     assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
     assert C.sizeof(_lib.UmbGemmFused) == 144
     assert C.sizeof(_lib.UmbGemmLL) == 152
@@ -51,6 +51,26 @@ def test_gemm_plan_is_token_count_free(lib):
         assert (N // 16) % R.value == 0 and 1 <= S.value <= 16 and (K // 128) >= S.value
         lib.umb_gemm_plan(N, K, awq, 1, C.byref(R), C.byref(S))
         assert S.value == 1
+
+
+def test_gemm_plan2_balances_whole_rounds(lib):
+    """umb_gemm_plan2: tiles per block / row-reduce split count.  The 70B gate/up (3584 n-tiles) runs 512 blocks of 7
+    tiles (two per CU) instead of 448 of 8; shapes that already tile the chip keep the round-2 plan."""
+    import ctypes as C
+
+    def plan2(N, K, awq, s1=0):
+        v = [C.c_int() for _ in range(4)]
+        lib.umb_gemm_plan2(N, K, awq, s1, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+    R, S, tb, srow = plan2(57344, 8192, 1, 1)
+    assert (R, S, tb, srow) == (2, 1, 7, 0) and ((57344 // 16 + 6) // 7) * S == 512
+    assert plan2(8192, 8192, 1) == (2, 8, 0, 0)                          # 70B o: the runtime's row-reduce rule caps S at 4
+    assert plan2(8192, 28672, 1) == (2, 8, 0, 0)                         # 70B down: 64 x 8 = 512 blocks already
+    assert plan2(10240, 8192, 1)[0] == 2 and plan2(10240, 8192, 1)[2] == 0
+    for (N, K, awq) in ((3072, 2048, 0), (16384, 2048, 0), (128256, 2048, 0), (6144, 4096, 0)):     # dense: unchanged
+        R0, S0 = C.c_int(), C.c_int()
+        lib.umb_gemm_plan(N, K, awq, 0, C.byref(R0), C.byref(S0))
+        assert plan2(N, K, awq) == (R0.value, S0.value, 0, 0)
 
 
 def test_ll_plan_is_shape_only_and_consistent(lib):

@@ -26,7 +26,8 @@ def dtype_code(dt: torch.dtype) -> int:
 
 class UmbLinear(C.Structure):
     _fields_ = [("w", C.c_void_p), ("meta", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
-                ("awq", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("pad_", C.c_int32)]
+                ("awq", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("tb", C.c_int32), ("S_row", C.c_int32),
+                ("pad_", C.c_int32)]
 
 
 class UmbLayer(C.Structure):
@@ -97,6 +98,7 @@ SIGNATURES = {
     "umb_repack_dense": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "umb_awq_repack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_plan": [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)],
+    "umb_gemm_plan2": [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "umb_gemm_wide_split": [_I, _I, _I],
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_fused": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(UmbGemmFused), _I, _P],
@@ -137,7 +139,7 @@ SIGNATURES = {
     "umb_bench_launch": [_I, _I, _P, _P],
     "umb_version": [],
 }
-_VOID = {"umb_gemm_plan", "umb_ll_plan"}
+_VOID = {"umb_gemm_plan", "umb_gemm_plan2", "umb_ll_plan"}
 _STR = {"umb_version"}
 
 _lib = None

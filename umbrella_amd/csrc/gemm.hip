@@ -255,6 +255,15 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
 
 enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 };
 
+// -DUMB_GEMM_TRACE (scripts/r3/gemm_trace.py builds a second library with it): wave 0 of every block stamps the constant
+// 100 MHz clock at its phase boundaries into fx.counters (8 x u64 per block; unused by the direct epilogues).
+#ifdef UMB_GEMM_TRACE
+#define UMB_STAMP(i) do { if (threadIdx.x == 0 && fx.counters) \
+    reinterpret_cast<unsigned long long*>(fx.counters)[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define UMB_STAMP(i) do {} while (0)
+#endif
+
 // Optional fused work around the GEMM (all pointers may be null).  Passed by value.
 //  * ssq_in : [T][ssq_groups] partial sums of squares of the producer's residual stream.  The RMSNorm weight is
 //    already folded into x by the producer (x = h * w), the per-token factor rsqrt(mean(h^2) + eps) commutes with
@@ -276,8 +285,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
                                                           const unsigned char* __restrict__ meta,
                                                           const u16* __restrict__ x, int ldx,
                                                           float* __restrict__ out, int T, int Ttot, int N, int K,
-                                                          int S, int epi, GemmFused fx) {
+                                                          int S, int epi, int tb, GemmFused fx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  UMB_STAMP(0);
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   constexpr int F = CB * TT * 4;           // 1 KiB fragments per chunk
   constexpr int FPW = F / 4;               // fragments staged per wave
@@ -285,11 +295,20 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int NT = N / 16;
-  const int nblk = (NT + 4 * R - 1) / (4 * R);
+  // tb n-tiles per block (4 R by default).  One CU streams ~25 GB/s whatever runs on it, so a launch is as fast as its
+  // busiest CU: tb is chosen by the host so that nblk * S blocks are whole rounds of 2 per CU (70B gate/up: 3584 tiles =
+  // 512 x 7, not 448 x 8 -- the 64 CUs with one block sat idle half the launch).  With tb < 4 R the last wave slots of a
+  // block are empty; pairs (R = 2) start at even GLOBAL tile indices, so the two tiles of a wave stay adjacent in the
+  // [N/64][K/128][4] tile order and in the metadata (a block whose first tile is odd gives wave 0 a single tile).
+  const int nblk = (NT + tb - 1) / tb;
   const int sp = blockIdx.x / nblk;
   const int nb = blockIdx.x % nblk;
-  const int nt0 = (nb * 4 + wv) * R;
-  const bool active = nt0 < NT;            // NT % R == 0 (host guarantees)
+  const int first = nb * tb;
+  const int odd = (R == 2) ? (first & 1) : 0;
+  const int wstart = first + wv * R - odd;
+  const int nt0 = max(wstart, first);                                   // this wave's first tile
+  const int ntiles = max(0, min(min(wstart + R, first + tb), NT) - nt0);  // 0 .. R
+  const bool active = ntiles > 0;
   const int KB = K / 128;
   const int per = (KB + S - 1) / S;
   const int kb0 = sp * per;
@@ -312,8 +331,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   __amdgpu_buffer_rsrc_t rw[R], rm[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int nt = active ? nt0 + r : 0;
-    const bool live = active && nkb > 0;
+    const int nt = r < ntiles ? nt0 + r : 0;
+    const bool live = r < ntiles && nkb > 0;
     if (AWQ) {
       const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);        // tile order [N/64][K/128][4]
       rw[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp + tile0 * 64), 0,
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     const int nt = active ? nt0 : 0;
     const long tile0 = ((long)(nt >> 2) * KB) * 4 + (nt & 3);
     rmeta = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(meta + tile0 * 64), 0,
-                                              (active && nkb > 0) ? (unsigned)(kb1 - 1) * 256u + R * 64u : 0u, 0x00020000);
+                                              (active && nkb > 0) ? (unsigned)(kb1 - 1) * 256u + ntiles * 64u : 0u, 0x00020000);
     if (lane < R * CB * 4) voff_m = (lane / (R * 4)) * 256 + (lane % (R * 4)) * 16;
   }
   u32x4 xr[XD][FPW];
@@ -389,6 +408,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     store_x(xr[XH], c);
     if (AWQ) *reinterpret_cast<u32x4*>(ms + H * MSLOT + lane * 16) = mr[H];
     __syncthreads();
+    if (c == 0) UMB_STAMP(2);
     // everything loaded from here on is for chunk c + 2 (x of TT > 1: c + 1), in the order it will be consumed
     load_x(xr[XH], c + XD);
     if (AWQ) mr[H] = load_m(c + 2);
@@ -405,6 +425,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
           if (AWQ == 2) sg.m1[r] = *reinterpret_cast<const unsigned*>(mrec + j * 4);
         }
         stage_compute<P, AWQ, TT, R>(sg, xc + kl * TT * 4 * 64, lane, acc);
+#ifdef UMB_GEMM_TRACE
+        if (c == 0 && kl == 0) { asm volatile("" :: "v"(acc[0][0][0])); UMB_STAMP(3); }
+#endif
       }
       sload(sg, kb + PF);
     }
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   if (AWQ) mr[1] = load_m(1);
 #pragma unroll
   for (int i = CB; i < PF; ++i) sload(st[i], kb0 + i);
+  UMB_STAMP(1);
   // per-token 1/rms of the producer's residual stream (its loads overlap the weight stream)
   float inv[TT];
 #pragma unroll
@@ -447,6 +471,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   }
 
   // ------------------------------------------------------------------ direct epilogues (no cross-block step)
+  UMB_STAMP(4);
   if (epi <= EPI_SILU) {
     if (!active) return;
 #pragma unroll
@@ -455,6 +480,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
       if (tok < T) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+          if (r >= ntiles) continue;
           f32x4 v = acc[r][tt];
           if (epi == EPI_SILU) {
             // rows are interleaved (gate_m, up_m): act[tok][m] = silu(gate) * up, every step rounded to the
@@ -477,6 +503,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
         }
       }
     }
+#ifdef UMB_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UMB_STAMP(5);
+#endif
     return;
   }
 
@@ -981,12 +1011,40 @@ extern "C" void umb_gemm_plan(int N, int K, int awq, int force_s1, int* R_out, i
   *S_out = S;
 }
 
+// The full plan (see the header).  One CU streams ~25 GB/s whatever runs on it and one 4-wave block alone ~17 GB/s
+// (scripts/r3/gemm_trace.py: per-block phase stamps), so a launch wants whole rounds of 2 blocks per CU.  70B gate/up
+// (3584 n-tiles): 448 blocks of 8 tiles left 64 CUs with one block for the whole launch -> 512 blocks of 7 tiles, capped
+// at two per CU (launch_k): 46.1 -> 44.9 us inside the iteration graph (48.4 -> 44.8 us stand-alone).
+// S_row stays 0 (the runtime's rule): running the 70B o-projection with one tile per wave and its full 8 splits (1024
+// blocks instead of 256) was 2 us faster stand-alone and 3 us SLOWER inside the graph (GEMM 11.1 -> 12.1 us, the
+// row reduce reads 8 partials instead of 4) -- measured, not kept.
+extern "C" void umb_gemm_plan2(int N, int K, int awq, int force_s1, int* R_out, int* S_out, int* tb_out, int* S_row_out) {
+  int R, S;
+  umb_gemm_plan(N, K, awq, force_s1, &R, &S);
+  const int NT = N / 16;
+  int tb = 0;
+  static const bool off = getenv("UMB_PLAN2_OFF") != nullptr;                  // A/B: the round-2 plan
+  if (!off && R == 2) {
+    const int b8 = ((NT + 7) / 8) * S, b7 = ((NT + 6) / 7) * S;
+    if (b8 % 256 != 0 && b7 % 256 == 0) tb = 7;
+  }
+  *R_out = R; *S_out = S; *tb_out = tb; *S_row_out = 0;
+}
+
 template <typename P, int AWQ, int TT, int R, int CB>
 static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot, int N,
-                    int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
+                    int K, int S, int epi, const GemmFused& fx, hipStream_t st, int tb = 0) {
   const int NT = N / 16;
-  const int nblk = (NT + 4 * R - 1) / (4 * R);
+  if (tb <= 0 || tb > 4 * R) tb = 4 * R;
+  const int nblk = (NT + tb - 1) / tb;
   size_t smem = (size_t)2 * CB * TT * 4 * 1024 + (AWQ ? 4 * 2 * 1024 : 0);   // x chunks (double buffered) + staged int4 metadata
+  // experiment knob UMB_LDS_KB: ask for at least that much dynamic LDS per block, which caps the blocks a CU admits
+  // (160 KiB per CU: 56 -> 2 blocks, 84 -> 1)
+  static const int lds_kb = getenv("UMB_LDS_KB") ? atoi(getenv("UMB_LDS_KB")) : 0;
+  if (lds_kb > 0 && smem < (size_t)lds_kb * 1024) smem = (size_t)lds_kb * 1024;
+  // a launch of exactly two blocks per CU: ask for 56 KiB of LDS so that no CU admits a third (the registers would
+  // allow it) and leaves another with one -- every CU then streams the same bytes
+  if (lds_kb == 0 && nblk * S == 512 && smem < 56 * 1024) smem = 56 * 1024;
   if (smem > 64 * 1024) {
     static bool once = false;      // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!once) {
@@ -996,23 +1054,24 @@ static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, flo
     }
   }
   hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB>), dim3((unsigned)(nblk * S)), dim3(256), smem, st,
-                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, fx);
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, tb, fx);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }
 
 template <typename P, int AWQ, int TT, int CB>
 static int launch_r(int R, const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot,
-                    int N, int K, int S, int epi, const GemmFused& fx, hipStream_t st) {
+                    int N, int K, int S, int epi, const GemmFused& fx, hipStream_t st, int tb = 0) {
   if ((N / 16) % R) return UMB_EINVAL;
-  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st);
-  if (R == 2 && epi <= EPI_SILU) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st);
+  if (epi > EPI_SILU) tb = 0;                                          // the in-kernel split epilogues index counters by 4-tile block
+  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
+  if (R == 2 && epi <= EPI_SILU) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
   return UMB_EINVAL;
 }
 
 template <typename P, int AWQ>
 static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int N, int K, int R,
-                     int S, int epi, const GemmFused& fx0, hipStream_t st) {
+                     int S, int epi, const GemmFused& fx0, hipStream_t st, int tb = 0) {
   // tokens beyond 64 go through further launches (weights re-read from L2/HBM)
   const long ostride = (epi == EPI_SILU) ? (long)(N / 2) / 2 : (long)N;   // out rows in units of float
   int tdone = 0;
@@ -1053,7 +1112,7 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     static const int cb1 = getenv("UMB_CB") ? atoi(getenv("UMB_CB")) : UMB_CB1;
     static const int cb2 = getenv("UMB_CB2") ? atoi(getenv("UMB_CB2")) : 1;      // 16 layers of the 70B at T = 31: 3.50 (CB 4) / 2.79 / 2.78 ms
     static const int cb4 = getenv("UMB_CB4") ? atoi(getenv("UMB_CB4")) : 1;      // T = 64: 4.96 (CB 2) / 4.60 ms
-#define UMB_LR(TTV, CBV) rc = launch_r<P, AWQ, TTV, CBV>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st)
+#define UMB_LR(TTV, CBV) rc = launch_r<P, AWQ, TTV, CBV>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st, tb)
     if (tn <= 16) { if (cb1 == 1) UMB_LR(1, 1); else if (cb1 == 2) UMB_LR(1, 2); else UMB_LR(1, 4); }
     else if (tn <= 32) { if (cb2 == 1) UMB_LR(2, 1); else if (cb2 == 2) UMB_LR(2, 2); else UMB_LR(2, 4); }
     else { if (cb4 == 1) UMB_LR(4, 1); else UMB_LR(4, 2); }
@@ -1077,8 +1136,14 @@ struct UmbGemmFusedC {
 extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N,
                               int K, int awq, int S, int R, int epi, const UmbGemmFusedC* fxc, int dtype,
                               hipStream_t st) {
+  // R: low byte = n-tiles per wave; bits 8..15 = n-tiles per block (0: 4 R), the plan's balance knob (umb_gemm_plan2)
+  int tb = (R >> 8) & 0xff;
+  R &= 0xff;
+  static const int tb_env = getenv("UMB_TB") ? atoi(getenv("UMB_TB")) : 0;     // experiments
+  if (tb_env > 0) tb = tb_env;
   if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 4 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
-  if (awq && (N % 64 || (R != 1 && (N / 16) % (4 * R)))) return UMB_EINVAL;
+  if (awq && (N % 64 || (R != 1 && (N / 16) % 2))) return UMB_EINVAL;
+  if (tb < 0 || tb > 4 * R) tb = 0;
   GemmFused fx = {};
   if (fxc) {
     fx.ssq_stride = fxc->pad0; fx.x_fm = fxc->pad1 & 1; fx.out_fm = (fxc->pad1 >> 1) & 1;
@@ -1104,10 +1169,10 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   // T > 64 (matrix-pipe bound verify GEMMs) and UMB_AWQ_EXACT=1: exact dequant, W = fp16((q - z) * s) bit for bit.
   static const bool awq_exact = getenv("UMB_AWQ_EXACT") != nullptr;
   if (awq && dtype == UMB_F16 && (awq_exact || T > 64))
-    return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
+    return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st, tb);
   DISPATCH_DTYPE(dtype, {
-    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
-    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st);
+    if (awq) return launch_tt<P, 1>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st, tb);
+    return launch_tt<P, 0>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st, tb);
   })
 }
 

@@ -30,6 +30,7 @@ static inline int dbg_sync(const char* what, hipStream_t st) {
 // 8B-AWQ down keeps 8 of its planned 16).  A function of the layer shape only, like the plan itself.
 static inline int eff_s(const UmbLinear& l, int T, bool row_reduce = false) {
   int S = umb_gemm_wide_split(T, l.N, l.S);
+  if (row_reduce && T <= 64 && l.S_row > 0) return l.S_row;       // the plan's measured choice (umb_gemm_plan2)
   if (row_reduce && T <= 64) {
     const int cap = l.K / 1792 > 4 ? l.K / 1792 : 4;
     const int nblk = l.N / (64 * (l.R > 0 ? l.R : 1));        // 64 R rows per block: never drop below one block per CU
@@ -40,7 +41,8 @@ static inline int eff_s(const UmbLinear& l, int T, bool row_reduce = false) {
 
 static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int T, int dtype, hipStream_t st, int epi,
                       const UmbGemmFused* fx, bool row_reduce = false) {
-  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, eff_s(l, T, row_reduce), l.R, epi, fx, dtype, st);
+  return umb_gemm_fused(out, x, ldx, l.w, l.meta, T, l.N, l.K, l.awq, eff_s(l, T, row_reduce), l.R | (l.tb << 8), epi, fx, dtype,
+                        st);
 }
 
 // embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h

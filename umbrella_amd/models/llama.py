@@ -51,9 +51,14 @@ class PackedLinear:
 
     def __init__(self, N, K, awq, w, meta, force_s1=False):
         self.N, self.K, self.awq, self.w, self.meta = N, K, int(awq), w, meta
-        R, S = C.c_int(0), C.c_int(0)
-        _lib.load().umb_gemm_plan(N, K, self.awq, int(force_s1), C.byref(R), C.byref(S))
-        self.R, self.S = R.value, S.value
+        R, S, tb, srow = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.load().umb_gemm_plan2(N, K, self.awq, int(force_s1), C.byref(R), C.byref(S), C.byref(tb), C.byref(srow))
+        self.R, self.S, self.tb, self.S_row = R.value, S.value, tb.value, srow.value
+
+    @property
+    def Rtb(self) -> int:
+        """the R argument of umb_gemm / umb_gemm_fused: n-tiles per wave | n-tiles per block << 8"""
+        return self.R | (self.tb << 8)
 
     @staticmethod
     def packed_bytes(N, K, awq):
@@ -96,7 +101,7 @@ class PackedLinear:
         s = UmbLinear()
         s.w = self.w.data_ptr() if w_ptr is None else w_ptr
         s.meta = (self.meta.data_ptr() if self.meta is not None else 0) if meta_ptr is None else meta_ptr
-        s.N, s.K, s.awq, s.R, s.S = self.N, self.K, self.awq, self.R, self.S
+        s.N, s.K, s.awq, s.R, s.S, s.tb, s.S_row = self.N, self.K, self.awq, self.R, self.S, self.tb, self.S_row
         return s
 
     def apply_silu(self, x: torch.Tensor) -> torch.Tensor:
@@ -104,7 +109,7 @@ class PackedLinear:
         assert getattr(self, "interleaved", False) and self.S == 1
         T = x.shape[0]
         act = torch.empty(T, self.N // 2, dtype=x.dtype, device=x.device)
-        _lib.call("umb_gemm", act, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, 1, self.R, 2,
+        _lib.call("umb_gemm", act, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, 1, self.Rtb, 2,
                   _lib.dtype_code(x.dtype))
         return act
 
@@ -124,7 +129,7 @@ class PackedLinear:
         """x [T, K] 16-bit -> fp32 [T, N] (split-K partials summed in split order)."""
         T = x.shape[0]
         part = torch.empty(self.S, T, self.N, dtype=torch.float32, device=x.device)
-        _lib.call("umb_gemm", part, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, self.S, self.R,
+        _lib.call("umb_gemm", part, x, x.stride(0), self.w, self.meta, T, self.N, self.K, self.awq, self.S, self.Rtb,
                   int(round_out), _lib.dtype_code(x.dtype))
         out = part[0]
         for s in range(1, self.S):
@@ -291,7 +296,7 @@ class Llama(LLMBase):
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
             lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
         if self.fused:
-            lin.R = 1                              # the in-kernel split epilogues own one n-tile per wave (ws.fused == 1
+            lin.R, lin.tb, lin.S_row = 1, 0, 0      # the in-kernel split epilogues own one n-tile per wave (ws.fused == 1
                                                    # whenever self.fused is set, whatever `sched` says: see reserve())
         lin.off_w, lin.off_meta = cursor, (cursor + wb if c.awq else None)
         return lin, cursor + wb + mb
