@@ -237,7 +237,7 @@ def kernel_roofline(eng, reps=40):
             epi = 2 if key == "gu" else 0
             out = act if key == "gu" else part
             launch = lambda ln: _lib.call("umb_gemm", out, x, x.stride(0), ln.w, ln.meta, T, N, K, ln.awq, S, ln.Rtb, epi, dt)
-            info = {"family": "split-K", "R": lin0.R, "S": S, "tiles_per_block": lin0.tb or 4 * lin0.R}
+            info = {"family": "split-K", "R": lin0.R, "S": S, "tiles_per_block": (lin0.tb & 0x7f) or 4 * lin0.R, "waves_per_block": 8 if lin0.tb & 0x80 else 4}
         for i in range(4):
             launch(m.layers[i % L][key])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -61,7 +61,8 @@ int umb_gemm_wide_split(int T, int N, int S_plan);
  * (umbrella/quantization/awq_utils.py:63-86).  epi: 0 raw fp32 partials; 1 round results to `dtype`
  * (what F.linear(...).float() yields for the lm_head, llama.py:133); 2 fused SiLU(gate)*up
  * (llama.py:107-110): needs S == 1 and interleaved rows, `out` is then 16-bit act[T][N/2].
- * R: low byte = n-tiles per wave; bits 8..15 = n-tiles per block `tb` of the plan (0: 4 R). */
+ * R: low byte = n-tiles per wave; bits 8..15 = the plan's `tb` word: n-tiles per block (0: 4 R), | 0x80 for 8-wave
+ * blocks (one block per CU sharing one staged copy of the activations). */
 int umb_gemm(void* out, const void* x, int ldx, const void* wpacked, const void* meta, int T, int N, int K,
              int awq, int S, int R, int epi, int dtype, umb_stream_t stream);
 

@@ -29,9 +29,10 @@ for name, N, K, il, S_eff in (("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 0
     ln = lins[0]
     x = torch.randn(T, K, device=dev).to(torch.float16)
     out = torch.empty(max(S_eff * T * N, T * N), dtype=torch.float32, device=dev)
-    nblk = (N // 16 + 4 * ln.R - 1) // (4 * ln.R)
+    tbv = (ln.tb & 0x7f) or 4 * ln.R
+    nblk = (N // 16 + tbv - 1) // tbv
     blocks = nblk * S_eff
-    trace = torch.zeros(blocks * 8, dtype=torch.int64, device=dev)
+    trace = torch.zeros(blocks * 16, dtype=torch.int64, device=dev)
     fx = _lib.UmbGemmFused()
     fx.counters = trace.data_ptr()
     epi = 2 if il else 0
@@ -40,9 +41,9 @@ for name, N, K, il, S_eff in (("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 0
         l = lins[i % ncopy]
         trace.zero_()
         torch.cuda.synchronize()
-        _lib.call("umb_gemm_fused", out, x, K, l.w, l.meta, T, N, K, 1, S_eff, l.R, epi, fx, dt)
+        _lib.call("umb_gemm_fused", out, x, K, l.w, l.meta, T, N, K, 1, S_eff, l.Rtb, epi, fx, dt)
         torch.cuda.synchronize()
-        t = trace.view(blocks, 8).cpu().numpy().astype(np.int64)
+        t = trace.view(blocks, 16).cpu().numpy().astype(np.int64)
         if i >= 2:
             res.append(t)
     print(f"== {name} N={N} K={K} S={S_eff} R={ln.R} blocks={blocks} ({per/1e6:.1f} MB)")
@@ -53,6 +54,10 @@ for name, N, K, il, S_eff in (("gu", 57344, 8192, 1, 1), ("down", 8192, 28672, 0
         for j, nm in enumerate(names):
             c = rel[:, j]
             print(f"   {nm:20s} min {c.min():6.2f}  p50 {np.median(c):6.2f}  p90 {np.percentile(c, 90):6.2f}  max {c.max():6.2f} us")
+        ch = (t[:, 6:16] - t0) / 100.0
+        ok = (t[:, 6:16] > 0).all(axis=0)
+        med = [f"{np.median(ch[:, i]):.2f}" if ok[i] else "-" for i in range(10)]
+        print("   chunk entry p50 (us): " + " ".join(med))
         dur = rel[:, 5] - rel[:, 0]
         print(f"   block lifetime       min {dur.min():6.2f}  p50 {np.median(dur):6.2f}  max {dur.max():6.2f} us; kernel span {rel[:,5].max():.2f} us; "
               f"late starters (start > 2 us): {(rel[:,0] > 2).sum()}")

@@ -54,8 +54,8 @@ def test_gemm_plan_is_token_count_free(lib):
 
 
 def test_gemm_plan2_balances_whole_rounds(lib):
-    """umb_gemm_plan2: tiles per block / row-reduce split count.  The 70B gate/up (3584 n-tiles) runs 512 blocks of 7
-    tiles (two per CU) instead of 448 of 8; shapes that already tile the chip keep the round-2 plan."""
+    """umb_gemm_plan2: tiles per block / waves per block.  The 70B gate/up (3584 n-tiles) runs 256 eight-wave blocks of
+    14 tiles (one per CU) instead of 448 four-wave blocks of 8; shapes that already tile the chip keep the round-2 plan."""
     import ctypes as C
 
     def plan2(N, K, awq, s1=0):
@@ -63,7 +63,8 @@ def test_gemm_plan2_balances_whole_rounds(lib):
         lib.umb_gemm_plan2(N, K, awq, s1, *[C.byref(x) for x in v])
         return tuple(x.value for x in v)
     R, S, tb, srow = plan2(57344, 8192, 1, 1)
-    assert (R, S, tb, srow) == (2, 1, 7, 0) and ((57344 // 16 + 6) // 7) * S == 512
+    assert (R, S, tb, srow) == (2, 1, 14 | 0x80, 0) and (57344 // 16) // 14 == 256     # one 8-wave block of 14 tiles per CU
+    assert plan2(28672, 4096, 1, 1) == (2, 1, 7, 0)                      # 8B-AWQ gate/up: 256 blocks of 7 tiles
     assert plan2(8192, 8192, 1) == (2, 8, 0, 0)                          # 70B o: the runtime's row-reduce rule caps S at 4
     assert plan2(8192, 28672, 1) == (2, 8, 0, 0)                         # 70B down: 64 x 8 = 512 blocks already
     assert plan2(10240, 8192, 1)[0] == 2 and plan2(10240, 8192, 1)[2] == 0

@@ -256,10 +256,12 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
 enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 };
 
 // -DUMB_GEMM_TRACE (scripts/r3/gemm_trace.py builds a second library with it): wave 0 of every block stamps the constant
-// 100 MHz clock at its phase boundaries into fx.counters (8 x u64 per block; unused by the direct epilogues).
+// 100 MHz clock at its phase boundaries into fx.counters (16 x u64 per block; unused by the direct epilogues): 0 entry,
+// 1 prologue loads issued, 2 first x chunk staged, 3 first k-block computed, 4 main loop left, 5 stores drained,
+// 6.. chunk c entered (c < 10).
 #ifdef UMB_GEMM_TRACE
 #define UMB_STAMP(i) do { if (threadIdx.x == 0 && fx.counters) \
-    reinterpret_cast<unsigned long long*>(fx.counters)[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    reinterpret_cast<unsigned long long*>(fx.counters)[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define UMB_STAMP(i) do {} while (0)
 #endif
@@ -280,8 +282,8 @@ struct GemmFused {
   u16* q_out; u16* kc; u16* vt; int Hq, Hkv, D, Lmax;
 };
 
-template <typename P, int AWQ, int TT, int R, int CB>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
+template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
                                                           const unsigned char* __restrict__ meta,
                                                           const u16* __restrict__ x, int ldx,
                                                           float* __restrict__ out, int T, int Ttot, int N, int K,
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   UMB_STAMP(0);
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   constexpr int F = CB * TT * 4;           // 1 KiB fragments per chunk
-  constexpr int FPW = F / 4;               // fragments staged per wave
+  static_assert(F % NWV == 0, "every wave stages the same number of activation fragments");
+  constexpr int FPW = F / NWV;             // fragments staged per wave (NWV waves per block: 4, or 8 = one block per CU
+                                           // whose waves share ONE staged copy of the activations instead of two)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   int voffx[FPW];
 #pragma unroll
   for (int i = 0; i < FPW; ++i) {
-    const int tok = (((i * 4) >> 2) % TT) * 16 + j;                     // (f >> 2) % TT with f = i*4 + wv: wv < 4 drops out
+    const int tok = (((i * NWV + wv) >> 2) % TT) * 16 + j;              // token tile of fragment f = i * NWV + wv
     voffx[i] = fx.x_fm ? lane * 16 : (tok < T ? (int)(((long)tok * ldx + g * 8) * 2) : (int)0x80000000);
   }
   // int4 metadata ({scale, zero} per row per k-block, 64 B per tile): ONE half-wave load per chunk brings the wave's
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   auto load_x = [&](u32x4 (&xq)[FPW], int c) {
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
-      const int f = i * 4 + wv;
+      const int f = i * NWV + wv;
       const int kb = kb0 + c * CB + f / (TT * 4);
       // FM: the B fragment of (k32-step, token tile) is one contiguous 1 KiB; row-major: 16 bytes of row tok at k
       const int soff = fx.x_fm ? ((kb * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 1024 : (kb * 128 + (f & 3) * 32) * 2;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
   };
   auto store_x = [&](const u32x4 (&xq)[FPW], int c) {
 #pragma unroll
-    for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * 4 + wv) * 64 + lane] = xq[i];
+    for (int i = 0; i < FPW; ++i) xs[((c & 1) * F + i * NWV + wv) * 64 + lane] = xq[i];
   };
   const int nfull = nkb > 0 ? nkb / CB : 0;  // chunks whose k-blocks all lie inside the slab
   auto chunk = [&](int c, auto half, auto guard) {
@@ -409,6 +413,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const u32x4* __restric
     if (AWQ) *reinterpret_cast<u32x4*>(ms + H * MSLOT + lane * 16) = mr[H];
     __syncthreads();
     if (c == 0) UMB_STAMP(2);
+#ifdef UMB_GEMM_TRACE
+    if (c < 10) UMB_STAMP(6 + c);
+#endif
     // everything loaded from here on is for chunk c + 2 (x of TT > 1: c + 1), in the order it will be consumed
     load_x(xr[XH], c + XD);
     if (AWQ) mr[H] = load_m(c + 2);
@@ -1024,36 +1031,41 @@ extern "C" void umb_gemm_plan2(int N, int K, int awq, int force_s1, int* R_out, 
   const int NT = N / 16;
   int tb = 0;
   static const bool off = getenv("UMB_PLAN2_OFF") != nullptr;                  // A/B: the round-2 plan
+  static const bool no_w8 = getenv("UMB_NO_W8") != nullptr;                    // A/B: 4-wave blocks only
   if (!off && R == 2) {
-    const int b8 = ((NT + 7) / 8) * S, b7 = ((NT + 6) / 7) * S;
+    const int b8 = ((NT + 7) / 8) * S, b7 = ((NT + 6) / 7) * S, b14 = ((NT + 13) / 14) * S;
     if (b8 % 256 != 0 && b7 % 256 == 0) tb = 7;
+    // exactly one 8-wave block of 14 tiles per CU: the CU's waves share ONE staged copy of the activations (two 4-wave
+    // blocks each load their own: 6.6 KB of x per 14 KiB of weights and chunk); flag 0x80 = 8 waves per block
+    if (!no_w8 && awq && b8 % 256 != 0 && b14 == 256) tb = 14 | 0x80;
+
   }
   *R_out = R; *S_out = S; *tb_out = tb; *S_row_out = 0;
 }
 
-template <typename P, int AWQ, int TT, int R, int CB>
+template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
 static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Ttot, int N,
                     int K, int S, int epi, const GemmFused& fx, hipStream_t st, int tb = 0) {
   const int NT = N / 16;
-  if (tb <= 0 || tb > 4 * R) tb = 4 * R;
+  if (tb <= 0 || tb > NWV * R) tb = NWV * R;
   const int nblk = (NT + tb - 1) / tb;
-  size_t smem = (size_t)2 * CB * TT * 4 * 1024 + (AWQ ? 4 * 2 * 1024 : 0);   // x chunks (double buffered) + staged int4 metadata
+  size_t smem = (size_t)2 * CB * TT * 4 * 1024 + (AWQ ? NWV * 2 * 1024 : 0);   // x chunks (double buffered) + staged int4 metadata
   // experiment knob UMB_LDS_KB: ask for at least that much dynamic LDS per block, which caps the blocks a CU admits
   // (160 KiB per CU: 56 -> 2 blocks, 84 -> 1)
   static const int lds_kb = getenv("UMB_LDS_KB") ? atoi(getenv("UMB_LDS_KB")) : 0;
   if (lds_kb > 0 && smem < (size_t)lds_kb * 1024) smem = (size_t)lds_kb * 1024;
   // a launch of exactly two blocks per CU: ask for 56 KiB of LDS so that no CU admits a third (the registers would
   // allow it) and leaves another with one -- every CU then streams the same bytes
-  if (lds_kb == 0 && nblk * S == 512 && smem < 56 * 1024) smem = 56 * 1024;
+  if (lds_kb == 0 && NWV == 4 && nblk * S == 512 && smem < 56 * 1024) smem = 56 * 1024;
   if (smem > 64 * 1024) {
     static bool once = false;      // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!once) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<P, AWQ, TT, R, CB>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<P, AWQ, TT, R, CB, NWV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return UMB_EHIP;
       once = true;
     }
   }
-  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB>), dim3((unsigned)(nblk * S)), dim3(256), smem, st,
+  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB, NWV>), dim3((unsigned)(nblk * S)), dim3(64 * NWV), smem, st,
                      (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, tb, fx);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
@@ -1064,8 +1076,16 @@ static int launch_r(int R, const void* wp, const void* meta, const u16* x, int l
                     int N, int K, int S, int epi, const GemmFused& fx, hipStream_t st, int tb = 0) {
   if ((N / 16) % R) return UMB_EINVAL;
   if (epi > EPI_SILU) tb = 0;                                          // the in-kernel split epilogues index counters by 4-tile block
-  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
-  if (R == 2 && epi <= EPI_SILU) return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
+  const bool w8 = (tb & 0x80) != 0;                                    // plan: 8 waves per block (one block per CU)
+  tb &= 0x7f;
+  if (R == 1) return launch_k<P, AWQ, TT, 1, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, w8 ? 0 : tb);
+  if (R == 2 && epi <= EPI_SILU) {
+    if constexpr ((CB * TT * 4) % 8 == 0 && AWQ == 1 && TT == 1) {     // instantiated where the plan uses it: int4, <= 16 rows
+      if (w8) return launch_k<P, AWQ, TT, 2, CB, 8>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
+    }
+    if (w8) tb = (tb + 1) / 2;                                         // the same balance with 4-wave blocks (14 -> 7 tiles)
+    return launch_k<P, AWQ, TT, 2, CB>(wp, meta, x, ldx, out, T, Ttot, N, K, S, epi, fx, st, tb);
+  }
   return UMB_EINVAL;
 }
 
@@ -1143,7 +1163,7 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   if (tb_env > 0) tb = tb_env;
   if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 4 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
   if (awq && (N % 64 || (R != 1 && (N / 16) % 2))) return UMB_EINVAL;
-  if (tb < 0 || tb > 4 * R) tb = 0;
+  if ((tb & 0x7f) > ((tb & 0x80) ? 8 : 4) * R) tb = 0;
   GemmFused fx = {};
   if (fxc) {
     fx.ssq_stride = fxc->pad0; fx.x_fm = fxc->pad1 & 1; fx.out_fm = (fxc->pad1 >> 1) & 1;
