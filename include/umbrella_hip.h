@@ -326,17 +326,22 @@ int umb_sum_splits(float* partial, int S, int64_t n, umb_stream_t stream);
  * host slabs are streamed into two device slabs on copy_stream, event-ordered against compute.
  * host_slabs[l] == NULL -> layer l is device resident (its UmbLayer pointers are used as is);
  * otherwise layers[l] pointers are offsets relative to the slab base. */
+#define UMB_MAX_SLABS 8
 typedef struct UmbOffload {
   void* const* host_slabs;          /* L entries */
   size_t slab_bytes;
-  void* dev_slab[2];
+  void* dev_slab[UMB_MAX_SLABS];    /* n_slabs device slabs used as a ring (the reference has two, llama.py:160-167) */
   umb_stream_t copy_stream;
-  void* ev_copied[2];               /* hipEvent_t */
-  void* ev_free[2];
-  int32_t* prefetched;              /* host int32[2] owned by the caller, initialised to {-1, -1} (NULL: no cross-forward
-                                       prefetch): the layers whose slabs the previous forward left in flight for this one.
-                                       The reference's (idx + 1) % num_layers copy (llama.py:203-209): the next forward's
-                                       first two layers stream while lm_head, sampling and the next draft tree run. */
+  void* ev_copied[UMB_MAX_SLABS];   /* hipEvent_t */
+  void* ev_free[UMB_MAX_SLABS];
+  int32_t* prefetched;              /* host int32[UMB_MAX_SLABS] owned by the caller, initialised to -1 (NULL: no
+                                       cross-forward prefetch): the layers whose slabs the previous forward left in flight
+                                       for this one.  The reference's (idx + 1) % num_layers copy (llama.py:203-209): the
+                                       next forward's first n_slabs streamed layers move while lm_head, sampling, the next
+                                       draft tree and -- with a device-resident prefix (num_cache_layers) -- the resident
+                                       layers run: more than two slabs keep the link busy through that prefix. */
+  int32_t n_slabs;                  /* 2 .. UMB_MAX_SLABS */
+  int32_t pad_;
 } UmbOffload;
 int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbOffload* off,
                               umb_stream_t stream);

@@ -55,14 +55,15 @@ if getattr(m, "_off", None) is not None:
     hs = [h for h in m.host_slabs if h is not None]
     with torch.cuda.stream(m.load_stream):
         for i, h in enumerate(hs[:4]):
-            m._dev_slabs[i & 1].copy_(h, non_blocking=True)
+            m._dev_slabs[i % len(m._dev_slabs)].copy_(h, non_blocking=True)
     torch.cuda.synchronize(); t0 = time.time()
     with torch.cuda.stream(m.load_stream):
         for i, h in enumerate(hs):
-            m._dev_slabs[i & 1].copy_(h, non_blocking=True)
+            m._dev_slabs[i % len(m._dev_slabs)].copy_(h, non_blocking=True)
     torch.cuda.synchronize(); t_stream = time.time() - t0
     out["pure_stream_ms_per_verify"] = round(t_stream * 1e3, 2)
     out["pure_stream_GBs"] = round(streamed / t_stream / 1e9, 1)
     out["iter_over_stream"] = round(dt / a.steps / t_stream, 4)
-    m._pf_state[0] = m._pf_state[1] = -1        # the slabs were overwritten: the next forward must refetch
+    for i in range(len(m._pf_state)):
+        m._pf_state[i] = -1                     # the slabs were overwritten: the next forward must refetch
 print(json.dumps(out))

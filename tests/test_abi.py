@@ -40,7 +40,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.UmbGemmFused) == 144
     assert C.sizeof(_lib.UmbGemmLL) == 152
     assert C.sizeof(_lib.UmbStep) == 8 + 8 * 8 + 6 * 4
-    assert C.sizeof(_lib.UmbOffload) == 8 + 8 + 16 + 8 + 16 + 16 + 8
+    assert C.sizeof(_lib.UmbOffload) == 8 + 8 + 64 + 8 + 64 + 64 + 8 + 8
 
 
 def test_gemm_plan_is_token_count_free(lib):

@@ -264,6 +264,23 @@ def test_awq_offload_dynamic_tiny(dev, ncache):
     assert again["generated_tokens"] == ref["generated_tokens"]
 
 
+@pytest.mark.parametrize("slabs,ncache", [(3, 0), (3, 1), (4, 0)])
+def test_offload_slab_ring(dev, monkeypatch, slabs, ncache):
+    """More than two device slabs (UMB_OFFLOAD_SLABS; the default with a device-resident prefix): the ring order, the
+    per-slab (copied, free) events and the cross-forward prefetch of the first `slabs` streamed layers leave the tokens
+    exactly the resident engine's, request after request."""
+    from hip_helpers import dynamic_engine
+    dtype = torch.float16
+    ref_eng, _ = dynamic_engine(G, dev, dtype, self_draft=False, width=8, num_beams=8, depth=4)
+    ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"]
+    monkeypatch.setenv("UMB_OFFLOAD_SLABS", str(slabs))
+    eng, _ = dynamic_engine(G, dev, dtype, self_draft=False, width=8, num_beams=8, depth=4, offload=True, num_cache_layers=ncache)
+    m = eng.target_model
+    assert m._off is not None and m.n_slabs == min(slabs, 4 - ncache) and len(m._dev_slabs) == m.n_slabs
+    for _ in range(3):
+        assert eng.generate(input_ids=PROMPT, max_new_tokens=40)["generated_tokens"] == ref
+
+
 def _full_width_70b_state(dev, layers, seed=3):
     from umbrella_amd.models.config import KNOWN
     from umbrella_amd.models.synthetic import linear_shapes, synth_awq_tensors

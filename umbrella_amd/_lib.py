@@ -86,10 +86,13 @@ class UmbTP(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p)]
 
 
+MAX_SLABS = 8
+
+
 class UmbOffload(C.Structure):
-    _fields_ = [("host_slabs", C.POINTER(C.c_void_p)), ("slab_bytes", C.c_size_t), ("dev_slab", C.c_void_p * 2),
-                ("copy_stream", C.c_void_p), ("ev_copied", C.c_void_p * 2), ("ev_free", C.c_void_p * 2),
-                ("prefetched", C.POINTER(C.c_int32))]
+    _fields_ = [("host_slabs", C.POINTER(C.c_void_p)), ("slab_bytes", C.c_size_t), ("dev_slab", C.c_void_p * MAX_SLABS),
+                ("copy_stream", C.c_void_p), ("ev_copied", C.c_void_p * MAX_SLABS), ("ev_free", C.c_void_p * MAX_SLABS),
+                ("prefetched", C.POINTER(C.c_int32)), ("n_slabs", C.c_int32), ("pad_", C.c_int32)]
 
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float

@@ -316,6 +316,8 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
                                          const UmbOffload* off, hipStream_t st) {
   const int lb = s->layer_begin, le = s->layer_end;
   if (lb < 0 || le > m->L || lb >= le) return UMB_EINVAL;
+  const int NS = off->n_slabs;
+  if (NS < 2 || NS > UMB_MAX_SLABS) return UMB_EINVAL;
   hipStream_t cs = (hipStream_t)off->copy_stream;
   auto issue_copy = [&](int l, int buf) -> int {
     // the slab may be overwritten only after the kernels that read it (ev_free is recorded on st)
@@ -325,29 +327,32 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
     if (hipEventRecord((hipEvent_t)off->ev_copied[buf], cs) != hipSuccess) return UMB_EHIP;
     return UMB_OK;
   };
-  // the first two streamed layers of this range, in order
-  int first[2] = {-1, -1};
-  for (int l = lb, n = 0; l < le && n < 2; ++l)
-    if (off->host_slabs[l]) first[n++] = l;
+  // the first NS streamed layers of this range, in order
+  int first[UMB_MAX_SLABS];
+  int nfirst = 0;
+  for (int l = lb; l < le && nfirst < NS; ++l)
+    if (off->host_slabs[l]) first[nfirst++] = l;
+  for (int i = nfirst; i < UMB_MAX_SLABS; ++i) first[i] = -1;
   // Cross-forward prefetch (the reference's loop copies layer (idx + 1) % num_layers, llama.py:203-209: layer 0 of the
   // NEXT forward is in flight while lm_head, sampling and the next draft tree run).  The previous forward left its
-  // epilogue copies of exactly these two layers in the slabs / on the copy stream: nothing to issue, and nothing on the
+  // epilogue copies of exactly these layers in the slabs / on the copy stream: nothing to issue, and nothing on the
   // compute stream gates them.
   int32_t* pf = off->prefetched;
-  const bool have = pf && pf[0] == first[0] && pf[1] == first[1] && first[0] >= 0;
+  bool have = pf != nullptr && nfirst > 0;
+  for (int i = 0; have && i < NS; ++i) have = pf[i] == first[i];
   int next = lb, issued = 0, used = 0;
   auto advance = [&]() { while (next < le && off->host_slabs[next] == nullptr) ++next; };
   advance();
   if (have) {
-    for (int i = 0; i < 2 && next < le; ++i) { ++issued; ++next; advance(); }
+    for (int i = 0; i < NS && next < le; ++i) { ++issued; ++next; advance(); }
   } else {
     // cold start (or a different layer range): order the copy stream behind everything already queued on st that may
-    // still read the slabs, then fetch the first two layers
-    for (int b = 0; b < 2; ++b)
+    // still read the slabs, then fetch the first NS layers
+    for (int b = 0; b < NS; ++b)
       if (hipEventRecord((hipEvent_t)off->ev_free[b], st) != hipSuccess) return UMB_EHIP;
-    for (int i = 0; i < 2 && next < le; ++i) { CK(issue_copy(next, issued & 1)); ++issued; ++next; advance(); }
+    for (int i = 0; i < NS && next < le; ++i) { CK(issue_copy(next, issued % NS)); ++issued; ++next; advance(); }
   }
-  if (pf) pf[0] = pf[1] = -1;
+  if (pf) for (int i = 0; i < UMB_MAX_SLABS; ++i) pf[i] = -1;
 
   const bool ll = use_ll(ws, s);
   int sg = 4;
@@ -356,7 +361,7 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
     UmbLayer cur = m->layers[l];
     int buf = -1;
     if (off->host_slabs[l]) {
-      buf = used & 1;
+      buf = used % NS;
       if (hipStreamWaitEvent(st, (hipEvent_t)off->ev_copied[buf], 0) != hipSuccess) return UMB_EHIP;
       cur = rebase(m->layers[l], off->dev_slab[buf]);
     }
@@ -368,13 +373,14 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       if (next < le) { CK(issue_copy(next, buf)); ++issued; ++next; advance(); }
     }
   }
-  // Epilogue: the next forward's first two slabs go out NOW, on the copy stream only -- each waits (on that stream) for
+  // Epilogue: the next forward's first NS slabs go out NOW, on the copy stream only -- each waits (on that stream) for
   // the ev_free of the last layer that read its slab, which was recorded above; the compute stream carries on with the
-  // lm_head, the sampling kernels and the next draft tree while the link is busy.  Slab parity restarts at 0.
-  if (pf && first[0] >= 0) {
-    CK(issue_copy(first[0], 0));
-    if (first[1] >= 0) CK(issue_copy(first[1], 1));
-    pf[0] = first[0]; pf[1] = first[1];
+  // lm_head, the sampling kernels, the next draft tree and the next forward's resident layers while the link is busy.
+  // Slab order restarts at 0.  (The slabs still in use by the last NS layers of THIS forward are reused in ring order,
+  // each copy gated by its own ev_free.)
+  if (pf && nfirst > 0) {
+    for (int i = 0; i < nfirst; ++i) CK(issue_copy(first[i], i));
+    for (int i = 0; i < NS; ++i) pf[i] = first[i];
   }
   if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;

@@ -401,9 +401,19 @@ class Llama(LLMBase):
         m.layers = C.cast(self._layer_structs, C.POINTER(UmbLayer))
         self._off = None
         if stream_any:
-            self._dev_slabs = [torch.empty(slab_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+            # Device slab ring.  Two slabs (the reference's count, llama.py:160-167) suffice when every layer streams: the
+            # link is the bottleneck and the compute of one layer hides inside the copy of the next.  With a device-resident
+            # prefix (num_cache_layers) the link would sit idle while those layers compute once both slabs are full, so the
+            # ring is as deep as that prefix is long in link time (70B-AWQ, 40 resident layers: 22 ms of compute = 2.8 slabs
+            # of 444 MB at 56 GB/s); UMB_OFFLOAD_SLABS overrides.
+            n_streamed = sum(1 for h in self.host_slabs if h is not None)
+            ns = 2 if self.num_cache_layers <= 0 else _lib.MAX_SLABS
+            ns = int(os.environ.get("UMB_OFFLOAD_SLABS", ns))
+            ns = max(2, min(_lib.MAX_SLABS, ns, max(2, n_streamed)))
+            self.n_slabs = ns
+            self._dev_slabs = [torch.empty(slab_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)]
             self.load_stream = torch.cuda.Stream(device=dev)
-            self._events = [torch.cuda.Event() for _ in range(4)]
+            self._events = [torch.cuda.Event() for _ in range(2 * ns)]
             for e in self._events:
                 e.record()                 # materialise the hipEvent_t handles
             arr = (C.c_void_p * L)(*[(h.data_ptr() if h is not None else None) for h in self.host_slabs])
@@ -411,13 +421,15 @@ class Llama(LLMBase):
             off = UmbOffload()
             off.host_slabs = C.cast(arr, C.POINTER(C.c_void_p))
             off.slab_bytes = slab_bytes
-            off.dev_slab[0], off.dev_slab[1] = self._dev_slabs[0].data_ptr(), self._dev_slabs[1].data_ptr()
+            off.n_slabs = ns
+            for i in range(ns):
+                off.dev_slab[i] = self._dev_slabs[i].data_ptr()
+                off.ev_copied[i] = self._events[i].cuda_event
+                off.ev_free[i] = self._events[ns + i].cuda_event
             off.copy_stream = self.load_stream.cuda_stream
-            off.ev_copied[0], off.ev_copied[1] = self._events[0].cuda_event, self._events[1].cuda_event
-            off.ev_free[0], off.ev_free[1] = self._events[2].cuda_event, self._events[3].cuda_event
-            # cross-forward prefetch state: which two layers the previous forward left streaming (UMB_OFFLOAD_PREFETCH=0:
+            # cross-forward prefetch state: which layers the previous forward left streaming (UMB_OFFLOAD_PREFETCH=0:
             # the reference-free baseline that refetches them behind the draft's kernels)
-            self._pf_state = (C.c_int32 * 2)(-1, -1)
+            self._pf_state = (C.c_int32 * _lib.MAX_SLABS)(*([-1] * _lib.MAX_SLABS))
             if os.environ.get("UMB_OFFLOAD_PREFETCH", "1") != "0":
                 off.prefetched = C.cast(self._pf_state, C.POINTER(C.c_int32))
             self._off = off
