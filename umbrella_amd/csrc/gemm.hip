@@ -898,13 +898,20 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
         const h2 q1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
         const h2 q2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
         const h2 q3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
+#ifdef UMB_VG_NODEQ       // ablation (wrong results): raw bits as the operand, no dequant arithmetic
+        wf[q][sx][0] = w ^ mm; wf[q][sx][1] = w8; wf[q][sx][2] = w; wf[q][sx][3] = w8 ^ mm;
+        (void)q0; (void)q1; (void)q2; (void)q3; (void)s2; (void)nz2; (void)nz16_2; (void)sixteenth;
+#else
         wf[q][sx][0] = __builtin_bit_cast(unsigned, (q0 + nz2) * s2);
         wf[q][sx][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q1, sixteenth, nz16_2) * s2);
         wf[q][sx][2] = __builtin_bit_cast(unsigned, (q2 + nz2) * s2);
         wf[q][sx][3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q3, sixteenth, nz16_2) * s2);
+#endif
       }
     }
+#ifndef UMB_VG_NOGLOAD      // ablation (wrong results): no global loads inside the loop
     if (ks + 1 < ks1) gload(ks + 1);
+#endif
     // activation fragments: the read for fragment i+1 is in flight while fragment i feeds 4 MFMAs
     const u32x4* sb = sB + (buf * NF) * 64 + lane;
     u32x4 bcur = sb[0];
@@ -914,14 +921,24 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
     for (int i = 0; i < NF; ++i) {
       const int t = i >> 1, sx = i & 1;
       u32x4 bnext = bcur;
+#ifndef UMB_VG_NOLDS        // ablation (wrong results): one fragment read per step
       if (i + 1 < NF) bnext = sb[(i + 1) * 64];
+#endif
+#ifdef UMB_VG_NOMFMA        // ablation (wrong results): one MFMA per fragment instead of four
+      acc[0][t] = P::mfma(wf[0][sx] ^ wf[1][sx] ^ wf[2][sx] ^ wf[3][sx], bcur, acc[0][t]);
+#else
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bcur, acc[q][t]);
+#endif
       bcur = bnext;
     }
     __builtin_amdgcn_s_setprio(0);
+#ifndef UMB_VG_NOSTORE      // ablation (wrong results)
     if (ks + 1 < ks1) sstore(buf ^ 1);
+#endif
+#ifndef UMB_VG_NOBAR        // ablation (wrong results)
     __syncthreads();
+#endif
   }
 
 #pragma unroll
