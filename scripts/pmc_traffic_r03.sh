@@ -19,12 +19,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if "skinny_gemm_kernel" not in r["Kernel_Name"] or r["Counter_Name"] != c:
             continue
-        agg.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+        agg.setdefault(f'{r["Grid_Size"]}x{r["Workgroup_Size"]}', []).append(float(r["Counter_Value"]))      # threads x block size
     raw[c] = {str(g): {"launches": len(v), "mean_KB": sum(v) / len(v)} for g, v in agg.items()}
-g = str(256 * 512)
+g = f"{256 * 512}x512"
 traffic = raw["FETCH_SIZE"][g]["mean_KB"] * 1024 * 2 + raw["WRITE_SIZE"][g]["mean_KB"] * 1024
 src = open(os.path.join(root, "umbrella_amd", "csrc", "gemm.hip"), "rb").read()
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python scripts/gemm_bench.py 70b (scripts/pmc_traffic.sh)",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python scripts/gemm_bench.py 70b (scripts/pmc_traffic_r03.sh)",
        "kernel": "skinny_gemm_kernel<F16, int4 (folded dequant), TT=1, R=2, 8 waves> gate_up N=57344 K=8192 T=13 (grid 256 x 512: one 14-tile block per CU)",
        "correction": "FETCH_SIZE [KB] x 1024 x 2 (gfx950 reports half the bytes of wide coalesced streaming reads); WRITE_SIZE [KB] x 1024",
        "raw": raw, "gate_up_traffic_bytes": traffic, "gate_up_algorithmic_bytes": 249561088,
