@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
 template <typename P, int D, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
                                                          const u16* __restrict__ vt, const int* __restrict__ prefix_p,
+                                                         int T, int Hq, int Hkv, int Lmax, int mask_words, int n_mask_keys,
                                                          const unsigned long long* __restrict__ mask_bits,
-                                                         int mask_words, int n_mask_keys, int T, int Hq, int Hkv,
-                                                         int Lmax, float scale, u16* __restrict__ out, int KBK,
+                                                         float scale, u16* __restrict__ out, int KBK,
                                                          float* __restrict__ po, float* __restrict__ pml,
                                                          unsigned* __restrict__ counters, int out_fm_tt) {
+  // argument order: the first 14 dwords (what the q / K loads need) are preloaded into SGPRs at wave launch
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ f32x4 so[NW][DT][64];
   __shared__ float sm[NW][16], sl[NW][16];
@@ -498,8 +499,8 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
     const dim3 grid1(Hkv, nqt, spans), block1(64 * nw);
 #define ATT1N_(DD, NWV)                                                                                           \
   hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,    \
-                     (const u16*)vt_cache, prefix_len, (const unsigned long long*)mask_bits, mask_words,           \
-                     n_mask_keys, T, Hq, Hkv, Lmax, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt)
+                     (const u16*)vt_cache, prefix_len, T, Hq, Hkv, Lmax, mask_words, n_mask_keys,                   \
+                     (const unsigned long long*)mask_bits, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt)
 #define ATT1_(DD)                                                                                                 \
   if (nw == 1) { ATT1N_(DD, 1); } else if (nw == 2) { ATT1N_(DD, 2); } else if (nw == 4) { ATT1N_(DD, 4); }       \
   else { ATT1N_(DD, 8); }

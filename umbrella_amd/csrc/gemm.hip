@@ -285,10 +285,15 @@ struct GemmFused {
 template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
                                                           const unsigned char* __restrict__ meta,
-                                                          const u16* __restrict__ x, int ldx,
-                                                          float* __restrict__ out, int T, int Ttot, int N, int K,
-                                                          int S, int epi, int tb, GemmFused fx) {
+                                                          const u16* __restrict__ x, int ldx, int T, int N, int K,
+                                                          int S, int tb, int Ttot, int epi_flags,
+                                                          float* __restrict__ out, GemmFused fx) {
+  // Argument order: the first 14 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
+  // hold everything the weight / activation streams need, so the first loads do not wait for a kernarg fetch.
+  // epi_flags = epi | x in FM layout << 8 | SiLU output in FM layout << 9.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int epi = epi_flags & 0xff;
+  const bool x_fm = (epi_flags & 0x100) != 0, out_fm = (epi_flags & 0x200) != 0;
   UMB_STAMP(0);
   u32x4* xs = reinterpret_cast<u32x4*>(smem);
   constexpr int F = CB * TT * 4;           // 1 KiB fragments per chunk
@@ -350,13 +355,13 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
     }
   }
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u16*>(x), 0, fx.x_fm ? (unsigned)(TT * 16 * 2) * (unsigned)K : (unsigned)(((long)(T - 1) * ldx + K) * 2),
+      const_cast<u16*>(x), 0, x_fm ? (unsigned)(TT * 16 * 2) * (unsigned)K : (unsigned)(((long)(T - 1) * ldx + K) * 2),
       0x00020000);
   int voffx[FPW];
 #pragma unroll
   for (int i = 0; i < FPW; ++i) {
     const int tok = (((i * NWV + wv) >> 2) % TT) * 16 + j;              // token tile of fragment f = i * NWV + wv
-    voffx[i] = fx.x_fm ? lane * 16 : (tok < T ? (int)(((long)tok * ldx + g * 8) * 2) : (int)0x80000000);
+    voffx[i] = x_fm ? lane * 16 : (tok < T ? (int)(((long)tok * ldx + g * 8) * 2) : (int)0x80000000);
   }
   // int4 metadata ({scale, zero} per row per k-block, 64 B per tile): ONE half-wave load per chunk brings the wave's
   // R tiles x CB k-blocks (16 B per lane), staged through a wave-private LDS slot and read back per k-block --
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
       const int f = i * NWV + wv;
       const int kb = kb0 + c * CB + f / (TT * 4);
       // FM: the B fragment of (k32-step, token tile) is one contiguous 1 KiB; row-major: 16 bytes of row tok at k
-      const int soff = fx.x_fm ? ((kb * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 1024 : (kb * 128 + (f & 3) * 32) * 2;
+      const int soff = x_fm ? ((kb * 4 + (f & 3)) * TT + ((f >> 2) % TT)) * 1024 : (kb * 128 + (f & 3) * 32) * 2;
       xq[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[i] + soff, 0, 0);
     }
   };
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
             const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
             u16* act = reinterpret_cast<u16*>(out);
             const int fa = (nt0 + r) * 8 + g * 2;
-            const long off = fx.out_fm ? ((((long)(fa >> 5) * TT + (tok >> 4)) * 64 + ((fa >> 3) & 3) * 16 + (tok & 15)) << 3) + (fa & 7)
+            const long off = out_fm ? ((((long)(fa >> 5) * TT + (tok >> 4)) * 64 + ((fa >> 3) & 3) * 16 + (tok & 15)) << 3) + (fa & 7)
                                        : (long)tok * (N / 2) + fa;
             *reinterpret_cast<unsigned*>(act + off) = pack2<P>(a0, a1);
           } else {
@@ -1083,7 +1088,8 @@ static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, flo
     }
   }
   hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB, NWV>), dim3((unsigned)(nblk * S)), dim3(64 * NWV), smem, st,
-                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, out, T, Ttot, N, K, S, epi, tb, fx);
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, N, K, S, tb, Ttot,
+                     epi | (fx.x_fm ? 0x100 : 0) | (fx.out_fm ? 0x200 : 0), out, fx);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

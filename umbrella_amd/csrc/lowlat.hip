@@ -78,17 +78,22 @@ __device__ __forceinline__ int ll_rowmap_qkv(int n, int D, int rope_heads) {
 // PF = k-blocks of weights in flight per wave; the host guarantees that every wave owns the same number nk = KB / WK
 // of k-blocks and that nk is a multiple of PF, so the main loop has no predicate at all.
 template <typename P, int AWQ, int TT, int R, int PF>
-__global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
+__global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const u32x4* __restrict__ a_w, const unsigned char* __restrict__ a_meta,
+                                                       const u32x4* __restrict__ a_x, int a_T, int a_N, int a_K, int a_WN,
+                                                       int a_WK, int a_epi, int a_row_from, int a_round_out,
+                                                       const LLArgs a) {
+  // the leading scalars (14 dwords) are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): the
+  // operand streams start without waiting for a kernarg fetch; `a` carries the epilogue's arguments
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NF = R * TT;                 // accumulator fragments per wave
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NW = blockDim.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  const int WK = a.WK;
+  const int WK = a_WK;
   const int wn = __builtin_amdgcn_readfirstlane(wv / WK), wk = wv - wn * WK;     // scalar (the division runs on the VALU)
-  const int NT = a.N / 16, KB = a.K / 128;
-  const int grp = blockIdx.x * a.WN + wn;
+  const int NT = a_N / 16, KB = a_K / 128;
+  const int grp = blockIdx.x * a_WN + wn;
   const int nt0 = grp * R;
   const bool active = nt0 < NT;
   const int nk = active ? KB / WK : 0;                       // this wave's k-blocks: kb = wk + i * WK (KB % WK == 0, nk % PF == 0)
@@ -101,9 +106,9 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
 
   // Streams: buffer loads with one descriptor per array, a 32-bit lane offset (VGPR) and a wave-uniform 32-bit byte
   // offset (SGPR) -- no per-load 64-bit VALU address arithmetic, no address registers.  (Arrays are < 4 GiB.)
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.w), 0, 0xffffffffu, 0x00020000);
-  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.x), 0, (unsigned)(TT * 16 * 2) * (unsigned)a.K, 0x00020000);   // exact size: see load_x
-  const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.meta), 0, 0xffffffffu, 0x00020000);
+  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a_w), 0, 0xffffffffu, 0x00020000);
+  const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a_x), 0, (unsigned)(TT * 16 * 2) * (unsigned)a_K, 0x00020000);   // exact size: see load_x
+  const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a_meta), 0, 0xffffffffu, 0x00020000);
   const int voff = lane * 16, voff_m = g * 16;
   unsigned wofs[R];                                                    // byte offset of k-block 0 of n-tile r
 #pragma unroll
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
   // exec juggling: the bounds check of the buffer instruction does it.
   int voff_x[TT];
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) voff_x[tt] = (tt * 16 + j < a.T) ? voff : (int)0x80000000;
+  for (int tt = 0; tt < TT; ++tt) voff_x[tt] = (tt * 16 + j < a_T) ? voff : (int)0x80000000;
   auto load_x = [&](u32x4 (&xb)[TT][4], int kb) {                      // the 4 x TT B fragments of k-block kb (from L2)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
   for (int tt = 0; tt < TT; ++tt) {
     float s = 0.f;
     const int t = tt * 16 + j;
-    if (a.ssq_in && t < a.T) {
+    if (a.ssq_in && t < a_T) {
       const float* sq = a.ssq_in + (long)t * a.ssq_in_stride;
       for (int q = wk * 4 + g; q < a.ssq_groups; q += 4 * WK) s += sq[q];
     }
@@ -309,18 +314,18 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const LLArgs a) {
     }
   }
 
-  const int N = a.N, T = a.T, epi = a.epi;
+  const int N = a_N, T = a_T, epi = a_epi;
   if (epi == LL_LOGITS) {
     float* out = reinterpret_cast<float*>(a.out);
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const int t = tt * 16 + j;
-      if (t >= T || t < a.row_from) continue;
+      if (t >= T || t < a_row_from) continue;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         f32x4 v = acc[r][tt] * inv[tt];
-        if (a.round_out) { v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
-        *reinterpret_cast<f32x4*>(out + (long)(t - a.row_from) * N + (nt0 + r) * 16 + g * 4) = v;
+        if (a_round_out) { v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
+        *reinterpret_cast<f32x4*>(out + (long)(t - a_row_from) * N + (nt0 + r) * 16 + g * 4) = v;
       }
     }
     return;
@@ -471,7 +476,8 @@ static int ll_launch_pf(const LLArgs& a, int NW, hipStream_t st) {
       once = true;
     }
   }
-  hipLaunchKernelGGL((ll_gemm_kernel<P, AWQ, TT, R, PF>), dim3((unsigned)blocks), dim3(64 * NW), smem, st, a);
+  hipLaunchKernelGGL((ll_gemm_kernel<P, AWQ, TT, R, PF>), dim3((unsigned)blocks), dim3(64 * NW), smem, st, a.w, a.meta, a.x, a.T, a.N, a.K,
+                     a.WN, a.WK, a.epi, a.row_from, a.round_out, a);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }
