@@ -13,9 +13,13 @@ with open(src) as f:
         name = r["Kernel_Name"]
         if pats and not any(p in name for p in pats):
             continue
-        grid = int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"])
-        wg = int(r["Workgroup_Size_X"]) if "Workgroup_Size_X" in r else int(r["Workgroup_Size"])
-        agg[(name.split("(")[0][:90], grid // wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if "Grid_Size_X" in r:      # work-items per dimension; the skinny GEMMs launch (n-tile groups, K splits) grids
+            blocks = 1
+            for d in "XYZ":
+                blocks *= max(1, int(r.get(f"Grid_Size_{d}", 1) or 1)) // max(1, int(r.get(f"Workgroup_Size_{d}", 1) or 1))
+        else:
+            blocks = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+        agg[(name.split("(")[0][:90], blocks)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 rows = sorted(((k, v) for k, v in agg.items()), key=lambda kv: -sum(kv[1]))
 with open(dst, "w", newline="") as f:
     w = csv.writer(f)

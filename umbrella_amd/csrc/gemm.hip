@@ -22,6 +22,8 @@
 //     reduces them in a fixed order -> results are bit-identical for any T
 //     (batch-invariant), which is what makes greedy spec == greedy AR exact.
 #include "common.h"
+#include <cstring>
+#include <cstdio>
 #include <type_traits>
 #include <cstdlib>
 #ifndef UMB_CB1
@@ -261,7 +263,7 @@ enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 
 // 6.. chunk c entered (c < 10).
 #ifdef UMB_GEMM_TRACE
 #define UMB_STAMP(i) do { if (threadIdx.x == 0 && fx.counters) \
-    reinterpret_cast<unsigned long long*>(fx.counters)[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+    reinterpret_cast<unsigned long long*>(fx.counters)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define UMB_STAMP(i) do {} while (0)
 #endif
@@ -286,10 +288,12 @@ template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
                                                           const unsigned char* __restrict__ meta,
                                                           const u16* __restrict__ x, int ldx, int T, int N, int K,
-                                                          int S, int tb, int Ttot, int epi_flags,
-                                                          float* __restrict__ out, GemmFused fx) {
+                                                          int per, int tb, int Ttot, int epi_flags,
+                                                          float* __restrict__ out, int S, GemmFused fx) {
   // Argument order: the first 14 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
   // hold everything the weight / activation streams need, so the first loads do not wait for a kernarg fetch.
+  // Grid = (n-tile groups, K splits) and `per` = k-blocks per split come from the host: no integer division here (three
+  // of them -- each a VALU reciprocal chain read back through v_readfirstlane -- stood in front of the first load).
   // epi_flags = epi | x in FM layout << 8 | SiLU output in FM layout << 9.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int epi = epi_flags & 0xff;
@@ -309,9 +313,8 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
   // 512 x 7, not 448 x 8 -- the 64 CUs with one block sat idle half the launch).  With tb < 4 R the last wave slots of a
   // block are empty; pairs (R = 2) start at even GLOBAL tile indices, so the two tiles of a wave stay adjacent in the
   // [N/64][K/128][4] tile order and in the metadata (a block whose first tile is odd gives wave 0 a single tile).
-  const int nblk = (NT + tb - 1) / tb;
-  const int sp = blockIdx.x / nblk;
-  const int nb = blockIdx.x % nblk;
+  const int sp = blockIdx.y;
+  const int nb = blockIdx.x;
   const int first = nb * tb;
   const int odd = (R == 2) ? (first & 1) : 0;
   const int wstart = first + wv * R - odd;
@@ -319,7 +322,6 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
   const int ntiles = max(0, min(min(wstart + R, first + tb), NT) - nt0);  // 0 .. R
   const bool active = ntiles > 0;
   const int KB = K / 128;
-  const int per = (KB + S - 1) / S;
   const int kb0 = sp * per;
   const int kb1 = min(KB, kb0 + per);
   const int nchunks = (kb1 - kb0 + CB - 1) / CB;
@@ -1062,7 +1064,18 @@ extern "C" void umb_gemm_plan2(int N, int K, int awq, int force_s1, int* R_out, 
     if (!no_w8 && awq && b8 % 256 != 0 && b14 == 256) tb = 14 | 0x80;
 
   }
-  *R_out = R; *S_out = S; *tb_out = tb; *S_row_out = 0;
+  int S_row = 0;
+  // experiments: UMB_PLAN_OVR="N,K:R,S,tb,Srow;..." replaces the plan of the named shapes (tb may carry the 0x80 flag)
+  static const char* ovr = getenv("UMB_PLAN_OVR");
+  if (ovr) {
+    for (const char* p = ovr; p && *p; ) {
+      int n = 0, k = 0, r = 0, sp = 0, t = 0, sr = 0;
+      if (sscanf(p, "%d,%d:%d,%d,%d,%d", &n, &k, &r, &sp, &t, &sr) == 6 && n == N && k == K) { R = r; S = sp; tb = t; S_row = sr; }
+      p = strchr(p, ';');
+      if (p) ++p;
+    }
+  }
+  *R_out = R; *S_out = S; *tb_out = tb; *S_row_out = S_row;
 }
 
 template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
@@ -1087,9 +1100,10 @@ static int launch_k(const void* wp, const void* meta, const u16* x, int ldx, flo
       once = true;
     }
   }
-  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB, NWV>), dim3((unsigned)(nblk * S)), dim3(64 * NWV), smem, st,
-                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, N, K, S, tb, Ttot,
-                     epi | (fx.x_fm ? 0x100 : 0) | (fx.out_fm ? 0x200 : 0), out, fx);
+  const int per = (K / 128 + S - 1) / S;
+  hipLaunchKernelGGL((skinny_gemm_kernel<P, AWQ, TT, R, CB, NWV>), dim3((unsigned)nblk, (unsigned)S), dim3(64 * NWV), smem, st,
+                     (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, N, K, per, tb, Ttot,
+                     epi | (fx.x_fm ? 0x100 : 0) | (fx.out_fm ? 0x200 : 0), out, S, fx);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }
