@@ -416,8 +416,18 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
     constexpr int H = decltype(half)::value;           // which half of the ring this chunk uses
     constexpr bool G = decltype(guard)::value;         // ragged tail: skip the k-blocks past the slab (compute only)
     constexpr int XH = XD == 2 ? H : 0;
-    store_x(xr[XH], c);
-    if (AWQ) *reinterpret_cast<u32x4*>(ms + H * MSLOT + lane * 16) = mr[H];
+    // EARLY (<= 16 rows: x rides two chunks ahead): chunk c's activations and metadata were written to LDS in the middle
+    // of chunk c - 1 (below), so nothing but the barrier stands between two chunks -- the ds_write -> lgkmcnt(0) latency
+    // sat on the critical path of every chunk of every wave of the block (64 chunks in a 70B gate/up launch)
+#ifdef UMB_NO_EARLY
+    constexpr bool EARLY = false;
+#else
+    constexpr bool EARLY = XD == 2;
+#endif
+    if constexpr (!EARLY) {
+      store_x(xr[XH], c);
+      if (AWQ) *reinterpret_cast<u32x4*>(ms + H * MSLOT + lane * 16) = mr[H];
+    }
     __syncthreads();
     if (c == 0) UMB_STAMP(2);
 #ifdef UMB_GEMM_TRACE
@@ -431,6 +441,12 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
     for (int kl = 0; kl < CB; ++kl) {
       const int kb = kb0 + c * CB + kl;
       Stage<P, AWQ, R>& sg = st[H * CB + kl];
+      if constexpr (EARLY) {
+        if (kl == CB - 1) {          // next chunk's operands: buffers (c + 1) & 1 were last read before this chunk's barrier
+          store_x(xr[1 - XH], c + 1);
+          if (AWQ) *reinterpret_cast<u32x4*>(ms + (1 - H) * MSLOT + lane * 16) = mr[1 - H];
+        }
+      }
       if (!G || kb < kb1) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -472,6 +488,12 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
       inv[tt] = rsqrtf(a / fx.ssq_dim + fx.eps);
     }
   }
+#ifndef UMB_NO_EARLY
+  if constexpr (XD == 2) {                             // EARLY: chunk 0's operands go to LDS here
+    store_x(xr[0], 0);
+    if (AWQ) *reinterpret_cast<u32x4*>(ms + lane * 16) = mr[0];
+  }
+#endif
   {
     int c = 0;
     for (; c + 2 <= nfull; c += 2) {                   // steady state: no branch, no predicate
