@@ -999,6 +999,250 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
   }
 }
 
+// ------------------------------------------------------------------ verify GEMM, explicit two-phase (ping-pong) schedule
+// The register-resident kernel above leaves the overlap of one wave's MFMA run with the other wave's dequant / loads /
+// staging to the wave scheduler (two independent blocks per CU + s_setprio).  Here the two live in ONE 8-wave workgroup as
+// two groups of four waves, each group a 256-row x TT*16-token work item of its own, and every step is cut into an X phase
+// (activations of this step -> LDS, dequant, next step's loads) and an M phase (fragment reads + 4 TT x 2 MFMAs) with a
+// workgroup barrier at every phase boundary; group 1 starts one barrier late, so on every SIMD one wave is in its M
+// phase while the other is in its X phase, in lockstep.  The groups of a workgroup take the same weight rows and
+// neighbouring token chunks when the chunk count is even (the second group's weight loads hit in L1 / L2 half a step
+// later: one HBM fetch per two chunks), otherwise neighbouring row blocks.  All loads unconditional (buffer descriptors).
+#ifndef UMB_PP_LM
+#define UMB_PP_LM 7
+#endif
+template <typename P, int AWQ, int TT>
+__global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __restrict__ wp,
+                                                             const unsigned char* __restrict__ meta,
+                                                             const u16* __restrict__ x, int ldx, int T, int Tv, int N, int K,
+                                                             int S, int epi, int pair_tc, float* __restrict__ out, GemmFused fx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NF = TT * 2;                                         // activation fragments per 64-k step
+  constexpr int FPW = (NF + 3) / 4;                                  // staged per wave
+  const int lane = threadIdx.x & 63;
+  const int wv8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wv8 >> 2, wv = wv8 & 3;
+  u32x4* sB = reinterpret_cast<u32x4*>(smem) + grp * NF * 64;        // one buffer per group: [TT][2 s][64]
+  const int j = lane & 15, g = lane >> 4;
+  const int nblk = N / 256;
+  const int nchunk = (Tv + TT * 16 - 1) / (TT * 16);
+  int nb, tc, sp;
+  if (pair_tc) {                                                     // groups: token chunks 2 q, 2 q + 1 of the same rows
+    const int hc = nchunk / 2;
+    nb = blockIdx.x % nblk; tc = 2 * ((blockIdx.x / nblk) % hc) + grp; sp = blockIdx.x / (nblk * hc);
+  } else {                                                           // groups: row blocks 2 q, 2 q + 1
+    const int hb = nblk / 2;
+    nb = 2 * (blockIdx.x % hb) + grp; tc = (blockIdx.x / hb) % nchunk; sp = blockIdx.x / (hb * nchunk);
+  }
+  const int KB = K / 128;
+  const int per = (KB + S - 1) / S;
+  const int ks0 = 2 * sp * per, ks1 = 2 * min(KB, sp * per + per);   // 64-k steps (same for both groups: same sp)
+  const int t0 = tc * TT * 16;
+
+  f32x4 acc[4][TT];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long tile_base = ((long)(nb * 4 + wv) * KB) * 4;             // int4 tile order [N/64][K/128][4]
+  const auto rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(AWQ ? wp + tile_base * 64 : wp + ((long)(nb * 4 + wv) * 4 * KB) * 256), 0,
+      AWQ ? (unsigned)KB * 4096u : (unsigned)KB * 16384u, 0x00020000);
+  const auto rmt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(AWQ ? meta + tile_base * 64 : (const unsigned char*)wp), 0,
+                                                     AWQ ? (unsigned)KB * 256u : 0u, 0x00020000);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(x), 0, (unsigned)(((long)(Tv - 1) * ldx + K) * 2), 0x00020000);
+  int voffx[FPW];
+#pragma unroll
+  for (int i = 0; i < FPW; ++i) {
+    const int f = i * 4 + wv, tok = t0 + (f >> 1) * 16 + j;
+    voffx[i] = (f < NF && tok < Tv) ? (int)(((long)tok * ldx + (f & 1) * 32 + g * 8) * 2) : (int)0x80000000;
+  }
+  // Loads are the X phase's long pole (phase trace, scripts/r3/vg_trace.py: 13 buffer loads per step cost ~940 cycles of
+  // issue with four waves of the CU in their X phase at once -- the texture-address path takes a wave64 load every ~16
+  // cycles whatever its width), so a 128-k block's int4 tile is ONE 16-byte load per n-tile and its metadata one load,
+  // shared by the block's two 64-k steps: 16 loads per two steps instead of 26.
+  u32x4 ra[4];                                                       // int4: the lane's four dwords (4 x k32) of this 128-k block, per n-tile
+  unsigned rm[4];
+  u32x4 rd[AWQ ? 1 : 4][AWQ ? 1 : 4];                                // dense: the four 16 x 32 tiles of this block, per n-tile
+  u32x4 rb[FPW];
+  const int kb0 = ks0 >> 1, kb1 = ks1 >> 1;
+  // single loads, so that the M phase can issue them one at a time between its MFMA groups
+  auto load_w1 = [&](int kb_, int q) {                               // int4 tile q of block kb_ (dense: its four k32 tiles)
+    const int kb = min(kb_, kb1 - 1);                                // past the slab: a harmless reload of its last block
+    if (AWQ) {
+      ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (kb * 4 + q) * 1024, 0);
+    } else {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        rd[AWQ ? 0 : q][AWQ ? 0 : s4] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (q * KB * 4 + kb * 4 + s4) * 1024, 2);
+    }
+  };
+  auto load_m1 = [&](int kb_, int q) {
+    const int kb = min(kb_, kb1 - 1);
+    if (AWQ) rm[q] = __builtin_amdgcn_raw_buffer_load_b32(rmt, j * 4, (kb * 4 + q) * 64, 0);
+  };
+  auto load_x1 = [&](int ks_, int i) {
+    const int ks = min(ks_, ks1 - 1);
+    rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[i], ks * 128, 0);
+  };
+  auto gload_w = [&](int kb_) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { load_w1(kb_, q); load_m1(kb_, q); }
+  };
+  auto gload_x = [&](int ks_) {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) load_x1(ks_, i);
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+      if (NF % 4 == 0 || i * 4 + wv < NF) sB[(i * 4 + wv) * 64 + lane] = rb[i];
+  };
+#ifdef UMB_VG_TRACE
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define VG_T(i) do { const unsigned long long tn = __builtin_readcyclecounter(); tsum[i] += tn - tprev; tprev = tn; } while (0)
+#else
+#define VG_T(i) do {} while (0)
+#endif
+  auto step = [&](auto hc, int kb) {
+    constexpr int HF = decltype(hc)::value;                          // which 64-k half of the block
+    // ---- X phase: this step's activations to LDS, its weights dequantised, the next loads issued
+    sstore();
+#ifdef UMB_VG_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    VG_T(0);
+    u32x4 wf[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!AWQ) { wf[q][0] = rd[AWQ ? 0 : q][AWQ ? 0 : HF * 2]; wf[q][1] = rd[AWQ ? 0 : q][AWQ ? 0 : HF * 2 + 1]; continue; }
+      const unsigned mm = rm[q];
+      const _Float16 sc = __builtin_bit_cast(_Float16, (u16)(mm & 0xffffu));
+      const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(mm >> 16));
+      const h2 s2 = {sc, sc};
+      const _Float16 nz = -((_Float16)1024.0f + zf), nz16 = -((_Float16)64.0f + zf);
+      const h2 nz2 = {nz, nz}, nz16_2 = {nz16, nz16};
+      const h2 sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+      unsigned magic = 0x64006400u;
+      asm volatile("" : "+v"(magic));
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const unsigned w = ra[q][HF * 2 + sx], w8 = w >> 8;
+        const h2 q0 = __builtin_bit_cast(h2, and_or(w, 0x000F000Fu, magic));
+        const h2 q1 = __builtin_bit_cast(h2, and_or(w, 0x00F000F0u, magic));
+        const h2 q2 = __builtin_bit_cast(h2, and_or(w8, 0x000F000Fu, magic));
+        const h2 q3 = __builtin_bit_cast(h2, and_or(w8, 0x00F000F0u, magic));
+#ifdef UMB_VG_NODEQ       // ablation (wrong results): raw bits as the operand, no dequant arithmetic
+        wf[q][sx][0] = w ^ mm; wf[q][sx][1] = w8; wf[q][sx][2] = w; wf[q][sx][3] = w8 ^ mm;
+        (void)q0; (void)q1; (void)q2; (void)q3; (void)s2; (void)nz2; (void)nz16_2; (void)sixteenth;
+#else
+        wf[q][sx][0] = __builtin_bit_cast(unsigned, (q0 + nz2) * s2);
+        wf[q][sx][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q1, sixteenth, nz16_2) * s2);
+        wf[q][sx][2] = __builtin_bit_cast(unsigned, (q2 + nz2) * s2);
+        wf[q][sx][3] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(q3, sixteenth, nz16_2) * s2);
+#endif
+      }
+    }
+#ifdef UMB_VG_TRACE
+    asm volatile("" :: "v"(wf[0][0][0]), "v"(wf[1][1][1]), "v"(wf[2][0][2]), "v"(wf[3][1][3]));
+#endif
+    VG_T(1);
+    // which loads the M phase issues (bit 0 activations, 1 weights, 2 metadata); the rest go out here
+    if (!(UMB_PP_LM & 1)) gload_x(2 * kb + HF + 1);
+    if (HF == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!(UMB_PP_LM & 2)) load_w1(kb + 1, q);
+        if (!(UMB_PP_LM & 4)) load_m1(kb + 1, q);
+      }
+    }
+    VG_T(2);
+    __syncthreads();
+    VG_T(3);
+    // ---- M phase.  Fragment reads run BD groups (of 4 MFMAs = 64 cycles) ahead of their use and are fenced there: left
+    // to itself the scheduler sinks every ds_read to just in front of its first MFMA
+#ifdef UMB_PP_BD
+    constexpr int BD = UMB_PP_BD;
+#else
+    constexpr int BD = 3;
+#endif
+    const u32x4* sb = sB + lane;
+    u32x4 bq[BD + 1];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) bq[i] = sb[i * 64];
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int t = i >> 1, sx = i & 1;
+      if (i + BD < NF) bq[(i + BD) % (BD + 1)] = sb[(i + BD) * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bq[i % (BD + 1)], acc[q][t]);
+      // The next loads go out HERE, one per MFMA group: issued from the X phase they cost ~90 cycles each (four waves of the
+      // CU queue on the texture-address path at once); between MFMAs the issue slots are free.  Registers: rb was
+      // stored at the start of this step's X phase, ra / rm were consumed by its dequant.
+      if ((UMB_PP_LM & 1) && (i & 1) == 1 && (i >> 1) < FPW) load_x1(2 * kb + HF + 1, i >> 1);
+      if ((UMB_PP_LM & 2) && HF == 1 && i >= NF - 8 && i < NF - 4) load_w1(kb + 1, i - (NF - 8));
+      if ((UMB_PP_LM & 4) && HF == 1 && i >= NF - 4) load_m1(kb + 1, i - (NF - 4));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef UMB_VG_TRACE
+    asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[3][TT - 1][3]));
+#endif
+    VG_T(4);
+    __syncthreads();
+    VG_T(5);
+  };
+
+  if (kb0 < kb1) {
+    gload_x(ks0);
+    gload_w(kb0);
+  }
+  if (grp == 1) __syncthreads();                                     // stagger: group 1 runs one phase behind group 0
+  for (int kb = kb0; kb < kb1; ++kb) {
+    step(std::integral_constant<int, 0>{}, kb);
+    step(std::integral_constant<int, 1>{}, kb);
+  }
+  if (grp == 0) __syncthreads();
+#ifdef UMB_VG_TRACE
+  if (lane == 0 && fx.counters) {
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(fx.counters) + ((size_t)blockIdx.x * 8 + wv8) * 8;
+    for (int i = 0; i < 6; ++i) tr[i] = tsum[i];
+    tr[6] = (unsigned long long)(ks1 - ks0);
+  }
+#endif
+
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    const int tok = t0 + t * 16 + j;
+    if (tok >= Tv) continue;
+    float inv = 1.f;
+    if (fx.ssq_in) {
+      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      float a = 0.f;
+      for (int q = 0; q < fx.ssq_groups; q += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q); a += v[0]; a += v[1]; a += v[2]; a += v[3]; }
+      inv = rsqrtf(a / fx.ssq_dim + fx.eps);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = acc[q][t];
+      const int ntile = (nb * 4 + wv) * 4 + q;
+      if (epi == EPI_SILU) {
+        v *= inv;
+        const float g0 = rnd<P>(v[0]), u0 = rnd<P>(v[1]), g1 = rnd<P>(v[2]), u1 = rnd<P>(v[3]);
+        const float a0 = rnd<P>(g0 / (1.f + __expf(-g0))) * u0, a1 = rnd<P>(g1 / (1.f + __expf(-g1))) * u1;
+        u16* act = reinterpret_cast<u16*>(out);
+        *reinterpret_cast<unsigned*>(act + (long)tok * (N / 2) + ntile * 8 + g * 2) = pack2<P>(a0, a1);
+      } else {
+        if (epi == EPI_ROUND) { v *= inv; v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]); }
+        *reinterpret_cast<f32x4*>(out + ((long)sp * T + tok) * N + ntile * 16 + g * 4) = v;
+      }
+    }
+  }
+}
+
 template <typename P, int AWQ>
 static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int Tv, int N,
                          int K, int S, int epi, const GemmFused& fx, hipStream_t st, bool tt9 = false) {
@@ -1007,6 +1251,22 @@ static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx
     static const bool plain = getenv("UMB_VGEMM_PLAIN") != nullptr;  // diagnostic: the LDS-shared 128 x 128 kernel
     // 256-row blocks: only when they still give every CU a block (small layers keep the 128-row kernel's finer grid)
     if (!plain && N % 256 == 0 && (N / 256) * nchunk * S >= 256) {
+      // two-phase schedule: two work items per 8-wave workgroup (UMB_VG_PP=0: the two-blocks-per-CU kernel, A/B)
+      static const bool no_pp = getenv("UMB_VG_PP") != nullptr && atoi(getenv("UMB_VG_PP")) == 0;
+      const int nch = tt9 ? (Tv + 143) / 144 : nchunk;
+      const int pair_tc = nch % 2 == 0;
+      if constexpr (AWQ == 2) if (!no_pp && (pair_tc || (N / 256) % 2 == 0)) {      // int4 only (a dense 128-k block of tiles is 64 registers)
+        const unsigned grid = (unsigned)((N / 256) * nch * S / 2);
+        if (tt9) {
+          hipLaunchKernelGGL((verify_gemm_pp_kernel<P, AWQ, 9>), dim3(grid), dim3(512), (size_t)2 * 18 * 64 * 16, st,
+                             (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, Tv, N, K, S, epi, pair_tc, out, fx);
+        } else {
+          hipLaunchKernelGGL((verify_gemm_pp_kernel<P, AWQ, 8>), dim3(grid), dim3(512), (size_t)2 * 16 * 64 * 16, st,
+                             (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, Tv, N, K, S, epi, pair_tc, out, fx);
+        }
+        UMB_LAUNCH_CHECK();
+        return UMB_OK;
+      }
       if (tt9) {
         hipLaunchKernelGGL((verify_gemm_r_kernel<P, AWQ, 9>), dim3((unsigned)((N / 256) * ((Tv + 143) / 144) * S)),
                            dim3(256), (size_t)2 * 18 * 64 * 16, st, (const u32x4*)wp, (const unsigned char*)meta, x, ldx,
