@@ -1172,20 +1172,27 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
 #pragma unroll
     for (int i = 0; i < BD; ++i) bq[i] = sb[i * 64];
     __builtin_amdgcn_s_setprio(1);
+#ifndef UMB_PP_NOFENCE
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       const int t = i >> 1, sx = i & 1;
       if (i + BD < NF) bq[(i + BD) % (BD + 1)] = sb[(i + BD) * 64];
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bq[i % (BD + 1)], acc[q][t]);
+#ifdef UMB_PP_NOFENCE
+#define PP_FENCE() do {} while (0)
+#else
+#define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
       // The next loads go out HERE, one per MFMA group: issued from the X phase they cost ~90 cycles each (four waves of the
       // CU queue on the texture-address path at once); between MFMAs the issue slots are free.  Registers: rb was
       // stored at the start of this step's X phase, ra / rm were consumed by its dequant.
       if ((UMB_PP_LM & 1) && (i & 1) == 1 && (i >> 1) < FPW) load_x1(2 * kb + HF + 1, i >> 1);
       if ((UMB_PP_LM & 2) && HF == 1 && i >= NF - 8 && i < NF - 4) load_w1(kb + 1, i - (NF - 8));
       if ((UMB_PP_LM & 4) && HF == 1 && i >= NF - 4) load_m1(kb + 1, i - (NF - 4));
-      __builtin_amdgcn_sched_barrier(0);
+      PP_FENCE();
     }
     __builtin_amdgcn_s_setprio(0);
 #ifdef UMB_VG_TRACE
