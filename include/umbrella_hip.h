@@ -104,6 +104,21 @@ typedef struct UmbGemmLL {
 } UmbGemmLL;
 int umb_gemm_ll(void* out, const void* x_fm, const void* wpacked, const void* meta, int T, int N, int K, int awq,
                 int epi, const UmbGemmLL* fx, int dtype, umb_stream_t stream);
+/* ------------------------------------------------------------------ row-streaming GEMV (T <= 4 rows: draft tree levels)
+ * out = epilogue(x @ w_rows^T) with x row-major [T][K] and w_rows a plain row-major [N][K] copy of the weights whose rows
+ * are in the packed layouts' order (umb_repack_rows: mode 1 (gate, up) pairs, mode 2 RoPE partner pairs).  Every load is
+ * issued at kernel start, a wave owns whole rows (8-row granularity: N = 2048 fills 256 CUs), v_dot2c accumulates in fp32.
+ * Same reference lines and the same epilogue arithmetic as umb_gemm_ll (epi 2 / 3 / 4), with ROW-MAJOR act / hw outputs and
+ * the sums of squares per workgroup: ssq_out[t][0 .. umb_gemv_groups(N, K)).  K must be 2048 or 8192.
+ * umb_gemv_ok: 1 if this (T, N, K, epi) is covered (0 with UMB_NO_GEMV=1). */
+int umb_gemv_ok(int T, int N, int K, int epi);
+int umb_gemv_groups(int N, int K);
+int umb_gemv(void* out, const void* x, const void* w_rows, int T, int N, int K, int epi, const UmbGemmLL* fx, int dtype,
+             umb_stream_t stream);
+/* out[n][k] = w[rowmap(n)][k]: rows in the order of the packed layouts (mode 0 identity, 1 interleaved gate/up, 2 q/k RoPE
+ * partner pairs over rope_heads heads of size D), 16-bit elements, K % 8 == 0 */
+int umb_repack_rows(void* out, const void* w, int N, int K, int mode, int D, int rope_heads, umb_stream_t stream);
+
 /* (R n-tiles per wave, WN row groups x WK K-slices = NW waves per block) for a [N][K] linear: shape-only, so a
  * token's result never depends on its batch mates; epi 4 writes N / 16 / R sums of squares per token. */
 void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int* WK_out, int* NW_out);
@@ -243,6 +258,8 @@ typedef struct UmbLinear {
   int32_t N, K, awq, R, S;
   int32_t tb, S_row;    /* umb_gemm_plan2: n-tiles per block (0: 4 R); split count under the row reduce (0: rule) */
   int32_t pad_;
+  const void* w_rows;   /* NULL, or the same weights as plain row-major [N][K] rows in packed order (umb_repack_rows): the
+                           GEMV family's operand for forwards of <= 4 rows (dense 16-bit, resident layers only) */
 } UmbLinear;
 
 typedef struct UmbLayer {

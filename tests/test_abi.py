@@ -33,9 +33,9 @@ def test_struct_layouts_match_header(lib):
     """ctypes mirrors must have the C struct sizes (LP64)."""
     import ctypes as C
     from umbrella_amd import _lib
-    assert C.sizeof(_lib.UmbLinear) == 48
-    assert C.sizeof(_lib.UmbLayer) == 4 * 48 + 24
-    assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 48 + 6 * 8
+    assert C.sizeof(_lib.UmbLinear) == 56
+    assert C.sizeof(_lib.UmbLayer) == 4 * 56 + 24
+    assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 56 + 6 * 8
     assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
     assert C.sizeof(_lib.UmbGemmFused) == 144
     assert C.sizeof(_lib.UmbGemmLL) == 152

@@ -27,7 +27,7 @@ def dtype_code(dt: torch.dtype) -> int:
 class UmbLinear(C.Structure):
     _fields_ = [("w", C.c_void_p), ("meta", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32),
                 ("awq", C.c_int32), ("R", C.c_int32), ("S", C.c_int32), ("tb", C.c_int32), ("S_row", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("pad_", C.c_int32), ("w_rows", C.c_void_p)]
 
 
 class UmbLayer(C.Structure):
@@ -106,6 +106,10 @@ SIGNATURES = {
     "umb_gemm": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "umb_gemm_fused": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(UmbGemmFused), _I, _P],
     "umb_gemm_ll": [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(UmbGemmLL), _I, _P],
+    "umb_gemv": [_P, _P, _P, _I, _I, _I, _I, C.POINTER(UmbGemmLL), _I, _P],
+    "umb_gemv_ok": [_I, _I, _I, _I],
+    "umb_gemv_groups": [_I, _I],
+    "umb_repack_rows": [_P, _P, _I, _I, _I, _I, _I, _P],
     "umb_ll_plan": [_I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "umb_ll_token_tiles": [_I],
     "umb_to_fm": [_P, _P, _I, _I, _I, _P],

@@ -481,7 +481,14 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
     if (fx.ssq_in && tok < T) {
       const float* sq = fx.ssq_in + (long)tok * (fx.ssq_stride ? fx.ssq_stride : fx.ssq_groups);
       float a = 0.f;
-      for (int q = 0; q < fx.ssq_groups; q += 4) {          // groups are a multiple of 4 or padded with zeros
+      int q = 0;
+      for (; q + 16 <= fx.ssq_groups; q += 16) {            // four loads per round trip (the GEMV schedule leaves 256 groups);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sq + q), v1 = *reinterpret_cast<const f32x4*>(sq + q + 4);   // same order
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(sq + q + 8), v3 = *reinterpret_cast<const f32x4*>(sq + q + 12);
+        a += v0[0]; a += v0[1]; a += v0[2]; a += v0[3]; a += v1[0]; a += v1[1]; a += v1[2]; a += v1[3];
+        a += v2[0]; a += v2[1]; a += v2[2]; a += v2[3]; a += v3[0]; a += v3[1]; a += v3[2]; a += v3[3];
+      }
+      for (; q < fx.ssq_groups; q += 4) {                    // groups are a multiple of 4 or padded with zeros
         const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q);
         a += v[0]; a += v[1]; a += v[2]; a += v[3];
       }

@@ -244,6 +244,63 @@ static int head_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
                      0, &fh, m->dtype, st);
 }
 
+// Schedule 3 (GEMV, T <= 4 rows of a low-latency model whose linears carry row-major copies): the low-latency schedule's
+// five launches with the four GEMMs on the row-streaming kernels of gemv.hip and ROW-MAJOR activations (ws->hw, ws->attn,
+// ws->act); the RMSNorm is split the same way (producer: hw = h * w and per-workgroup sums of squares; consumer: 1/rms).
+static inline bool use_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s) {
+  if (ws->fused != 2 || s->T > 4 || s->layer_begin >= s->layer_end) return false;
+  const UmbLayer& ly = m->layers[s->layer_begin];
+  if (!ly.qkv.w_rows || !ly.o.w_rows || !ly.gu.w_rows || !ly.down.w_rows || m->H % 64) return false;
+  if (!umb_gemv_ok(s->T, ly.qkv.N, ly.qkv.K, 3) || !umb_gemv_ok(s->T, ly.o.N, ly.o.K, 4) ||
+      !umb_gemv_ok(s->T, ly.gu.N, ly.gu.K, 2) || !umb_gemv_ok(s->T, ly.down.N, ly.down.K, 4)) return false;
+  const int og = umb_gemv_groups(ly.o.N, ly.o.K), dg = umb_gemv_groups(ly.down.N, ly.down.K);
+  return og <= ws->ssq_stride && dg <= ws->ssq_stride && og % 4 == 0 && dg % 4 == 0 && (m->H / 64) % 4 == 0;
+}
+static int prologue_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, int* groups,
+                       hipStream_t st) {
+  if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
+  *groups = m->H / 64;                         // umb_embed_prep: one sum of squares per 64 columns
+  return umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
+                        s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
+                        ws->hw, first_norm, ws->ssq, ws->ssq_stride, m->dtype, st);
+}
+static int layer_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                    const void* next_norm, int* groups, hipStream_t st) {
+  const int T = s->T, dt = m->dtype;
+  const size_t esz = 2;
+  char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
+  UmbGemmLL fq = {};
+  fq.ssq_in = ws->ssq; fq.ssq_groups = *groups; fq.ssq_in_stride = ws->ssq_stride; fq.ssq_dim = (float)m->H; fq.eps = m->eps;
+  fq.pos = ws->pos; fq.slot = ws->slot; fq.cosT = m->rope_cos; fq.sinT = m->rope_sin; fq.q_out = ws->q; fq.k_cache = kc;
+  fq.vt_cache = vt; fq.bias = ly.qkv_bias; fq.Hq = m->Hq; fq.Hkv = m->Hkv; fq.D = m->D; fq.Lmax = m->Lmax;
+  CK(umb_gemv(nullptr, ws->hw, ly.qkv.w_rows, T, ly.qkv.N, ly.qkv.K, 3, &fq, dt, st));
+  CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                   s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                   ws->attn_counters, dt, st));
+  UmbGemmLL fo = {};
+  fo.h = ws->h; fo.hw = ws->hw; fo.norm_w = ly.norm2; fo.ssq_out = ws->ssq; fo.ssq_out_stride = ws->ssq_stride;
+  CK(umb_gemv(nullptr, ws->attn, ly.o.w_rows, T, ly.o.N, ly.o.K, 4, &fo, dt, st));
+  UmbGemmLL fg = {};
+  fg.ssq_in = ws->ssq; fg.ssq_groups = umb_gemv_groups(ly.o.N, ly.o.K); fg.ssq_in_stride = ws->ssq_stride;
+  fg.ssq_dim = (float)m->H; fg.eps = m->eps;
+  CK(umb_gemv(ws->act, ws->hw, ly.gu.w_rows, T, ly.gu.N, ly.gu.K, 2, &fg, dt, st));
+  UmbGemmLL fd = {};
+  fd.h = ws->h; fd.hw = ws->hw; fd.norm_w = next_norm; fd.ssq_out = ws->ssq; fd.ssq_out_stride = ws->ssq_stride;
+  CK(umb_gemv(nullptr, ws->act, ly.down.w_rows, T, ly.down.N, ly.down.K, 4, &fd, dt, st));
+  *groups = umb_gemv_groups(ly.down.N, ly.down.K);
+  return UMB_OK;
+}
+static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int groups, hipStream_t st) {
+  if (s->head_from >= s->T) return UMB_OK;
+  const int rows = s->T - s->head_from;
+  const char* x = (const char*)ws->hw + (size_t)s->head_from * m->H * 2;
+  UmbGemmFused fh = {};
+  fh.ssq_in = ws->ssq + (size_t)s->head_from * ws->ssq_stride; fh.ssq_groups = groups; fh.pad0 = ws->ssq_stride;
+  fh.ssq_dim = (float)m->H; fh.eps = m->eps;
+  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, &fh);
+}
+
 static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
                  const void* next_norm, hipStream_t st) {
   return ws->fused == 1 ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st);
@@ -275,6 +332,16 @@ static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbSte
       CK(layer_split(m, ws, s, m->layers[l], l, nn, st, tp));
     }
     if (le == m->L) CK(head(m, ws, s, st));
+    return UMB_OK;
+  }
+  if (use_gv(m, ws, s)) {
+    int groups = 0;
+    CK(prologue_gv(m, ws, s, m->layers[lb].norm1, &groups, st));
+    for (int l = lb; l < le; ++l) {
+      const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
+      CK(layer_gv(m, ws, s, m->layers[l], l, nn, &groups, st));
+    }
+    if (le == m->L) CK(head_gv(m, ws, s, groups, st));
     return UMB_OK;
   }
   const bool ll = use_ll(ws, s);

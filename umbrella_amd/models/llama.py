@@ -102,6 +102,8 @@ class PackedLinear:
         s.w = self.w.data_ptr() if w_ptr is None else w_ptr
         s.meta = (self.meta.data_ptr() if self.meta is not None else 0) if meta_ptr is None else meta_ptr
         s.N, s.K, s.awq, s.R, s.S, s.tb, s.S_row = self.N, self.K, self.awq, self.R, self.S, self.tb, self.S_row
+        rows = getattr(self, "w_rows", None)          # row-major copy for the GEMV family (resident dense layers only)
+        s.w_rows = rows.data_ptr() if (rows is not None and w_ptr is None) else 0
         return s
 
     def apply_silu(self, x: torch.Tensor) -> torch.Tensor:
@@ -295,6 +297,14 @@ class Llama(LLMBase):
         else:
             w = torch.cat([fetch(prefix + n + ".weight", shapes[n], "linear").to(self.dtype) for n in names], dim=0)
             lin = PackedLinear.from_dense(w, out=w_view, interleave=il, rope=rope)
+            # forwards of <= 4 rows (the draft's tree levels) run on the row-streaming GEMV kernels (csrc/gemv.hip), which
+            # read a plain row-major copy of the weights with the packed layouts' row order.  Low-latency models only
+            # (small dense models: +1x their weight bytes), K in {2048, 8192}, resident layers; UMB_GEMV=0 disables.
+            if (self.sched == "ll" and not self.fused and not self.offload and K in (2048, 8192)
+                    and os.environ.get("UMB_GEMV", "1") != "0"):
+                lin.w_rows = torch.empty_like(w)
+                _lib.call("umb_repack_rows", lin.w_rows, w.contiguous(), N, K, 1 if il else (2 if rope else 0),
+                          rope[0] if rope else 0, rope[1] if rope else 0)
         if self.fused:
             lin.R, lin.tb, lin.S_row = 1, 0, 0      # the in-kernel split epilogues own one n-tile per wave (ws.fused == 1
                                                    # whenever self.fused is set, whatever `sched` says: see reserve())
@@ -468,7 +478,8 @@ class Llama(LLMBase):
         w["logits"] = torch.empty(logit_rows if self.is_last else 1, V if self.is_last else 8, dtype=torch.float32,
                                   device=dev)
         w["hw"] = torch.zeros(T, H, dtype=dt, device=dev)
-        self.ssq_stride = max(H // 16, 4)           # low-latency schedule: one sum of squares per 16-column tile
+        self.ssq_stride = max(H // 16, 256)         # low-latency schedule: one sum of squares per 16-column tile;
+                                                    # GEMV schedule: one per workgroup (<= 256)
         w["ssq"] = torch.zeros(T, self.ssq_stride, dtype=torch.float32, device=dev)
         maxn = max(N for (N, K, S) in self._plans.values())
         if not hasattr(self, "_counters"):          # self-resetting arrival counters (zero between launches)
