@@ -69,7 +69,7 @@ def test_gemv_residual_epilogue(dev, dtype, N, K, T):
     h0 = torch.randn(T, N, device=dev, generator=g).to(dtype)
     nw = (1 + 0.1 * torch.randn(N, device=dev, generator=g)).to(dtype)
     assert lib.umb_gemv_ok(T, N, K, 4) == 1
-    groups = lib.umb_gemv_groups(N, K)
+    groups = lib.umb_gemv_groups(T, N, K)
     stride = groups + 4
     for rep in range(2):
         h, hw = h0.clone(), torch.zeros(T, N, dtype=dtype, device=dev)
@@ -158,9 +158,9 @@ def test_gemv_batch_invariance(dev):
     x = torch.randn(4, K, device=dev, generator=g).to(dtype)
     h0 = torch.randn(4, N, device=dev, generator=g).to(dtype)
     nw = (1 + 0.1 * torch.randn(N, device=dev, generator=g)).to(dtype)
-    groups = _lib.load().umb_gemv_groups(N, K)
 
     def run(T):
+        groups = _lib.load().umb_gemv_groups(T, N, K)
         h, hw = h0[:T].clone(), torch.zeros(T, N, dtype=dtype, device=dev)
         ssq = torch.zeros(T, groups, device=dev)
         _lib.call("umb_gemv", None, x[:T].contiguous(), w, T, N, K, 4, _fx(h=h, hw=hw, norm_w=nw, ssq_out=ssq, ssq_out_stride=groups),
@@ -170,6 +170,7 @@ def test_gemv_batch_invariance(dev):
     for T in (1, 2, 3):
         part = run(T)
         assert all(torch.equal(a, b[:T]) for a, b in zip(part, full))
+
 
 
 def test_gemv_rejects_what_it_does_not_cover(dev):

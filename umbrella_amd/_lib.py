@@ -108,7 +108,7 @@ SIGNATURES = {
     "umb_gemm_ll": [_P, _P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(UmbGemmLL), _I, _P],
     "umb_gemv": [_P, _P, _P, _I, _I, _I, _I, C.POINTER(UmbGemmLL), _I, _P],
     "umb_gemv_ok": [_I, _I, _I, _I],
-    "umb_gemv_groups": [_I, _I],
+    "umb_gemv_groups": [_I, _I, _I],
     "umb_repack_rows": [_P, _P, _I, _I, _I, _I, _I, _P],
     "umb_ll_plan": [_I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "umb_ll_token_tiles": [_I],

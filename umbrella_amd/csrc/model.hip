@@ -253,7 +253,7 @@ static inline bool use_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbSt
   if (!ly.qkv.w_rows || !ly.o.w_rows || !ly.gu.w_rows || !ly.down.w_rows || m->H % 64) return false;
   if (!umb_gemv_ok(s->T, ly.qkv.N, ly.qkv.K, 3) || !umb_gemv_ok(s->T, ly.o.N, ly.o.K, 4) ||
       !umb_gemv_ok(s->T, ly.gu.N, ly.gu.K, 2) || !umb_gemv_ok(s->T, ly.down.N, ly.down.K, 4)) return false;
-  const int og = umb_gemv_groups(ly.o.N, ly.o.K), dg = umb_gemv_groups(ly.down.N, ly.down.K);
+  const int og = umb_gemv_groups(s->T, ly.o.N, ly.o.K), dg = umb_gemv_groups(s->T, ly.down.N, ly.down.K);
   return og <= ws->ssq_stride && dg <= ws->ssq_stride && og % 4 == 0 && dg % 4 == 0 && (m->H / 64) % 4 == 0;
 }
 static int prologue_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, int* groups,
@@ -282,13 +282,13 @@ static int layer_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
   fo.h = ws->h; fo.hw = ws->hw; fo.norm_w = ly.norm2; fo.ssq_out = ws->ssq; fo.ssq_out_stride = ws->ssq_stride;
   CK(umb_gemv(nullptr, ws->attn, ly.o.w_rows, T, ly.o.N, ly.o.K, 4, &fo, dt, st));
   UmbGemmLL fg = {};
-  fg.ssq_in = ws->ssq; fg.ssq_groups = umb_gemv_groups(ly.o.N, ly.o.K); fg.ssq_in_stride = ws->ssq_stride;
+  fg.ssq_in = ws->ssq; fg.ssq_groups = umb_gemv_groups(T, ly.o.N, ly.o.K); fg.ssq_in_stride = ws->ssq_stride;
   fg.ssq_dim = (float)m->H; fg.eps = m->eps;
   CK(umb_gemv(ws->act, ws->hw, ly.gu.w_rows, T, ly.gu.N, ly.gu.K, 2, &fg, dt, st));
   UmbGemmLL fd = {};
   fd.h = ws->h; fd.hw = ws->hw; fd.norm_w = next_norm; fd.ssq_out = ws->ssq; fd.ssq_out_stride = ws->ssq_stride;
   CK(umb_gemv(nullptr, ws->act, ly.down.w_rows, T, ly.down.N, ly.down.K, 4, &fd, dt, st));
-  *groups = umb_gemv_groups(ly.down.N, ly.down.K);
+  *groups = umb_gemv_groups(T, ly.down.N, ly.down.K);
   return UMB_OK;
 }
 static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int groups, hipStream_t st) {
