@@ -42,11 +42,11 @@ __device__ __forceinline__ int gv_rowmap_qkv(int n, int D, int rope_heads) {    
 
 // RW rows per wave and pass, KS k-slices of 2048 elements per row (K = KS * 2048), 8 waves = 8 / KS row-group slots.
 // Argument order: the leading scalars are preloaded into SGPRs (-amdgpu-kernarg-preload-count), the streams start at once.
-template <typename P, int RW, int KS, int EPI, int TN>
+template <typename P, int RW, int KS, int EPI>
 __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, const u16* __restrict__ x, int T, int N, int K,
                                                  int RB, GvArgs a) {
-  __shared__ float red[8][RW][TN];             // k-slice partials (TN = 4 or 8 token slots)
-  __shared__ float sred[8][TN];                // sums of squares per wave (GV_RESID)
+  __shared__ float red[8][RW][4];              // k-slice partials
+  __shared__ float sred[8][4];                 // sums of squares per wave (GV_RESID)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NSLOT = 8 / KS;
@@ -54,19 +54,19 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
   const int slot_w = KS == 1 ? wv : (wv / KS);
   const int ngrp = RB / RW;
   const int kbase = ks * 2048;
-  const int tl = lane & (TN - 1);              // the token this lane finishes (lanes 0..TN-1 do; the rest mirror them, unused)
-  const bool fin = lane < TN && lane < T;
+  const int tl = lane & 3;                     // the token this lane finishes (lanes 0..3 do; the rest mirror them, unused)
+  const bool fin = lane < 4 && lane < T;
   const int OOB = (int)0x80000000;
   // ---- every load of the kernel is an unconditional buffer load issued here, smallest first (loads return in order): the
   // producer's sums of squares, positions / slots, the activations, then the first pass's weights and epilogue operands.
   // Nothing waits behind a branch, so the compiler's vmcnt bookkeeping stays exact and the epilogue adds no memory round
   // trip of its own (a load behind a loop in front of the FMAs cost the q/k/v launch 4 us: 9.0 vs 4.9).
-  float sqv[TN][4];
+  float sqv[4][4];
   if constexpr (EPI != GV_RESID) {
     const auto rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ssq_in), 0,
                                                        a.ssq_in ? (unsigned)((T - 1) * a.ssq_in_stride + a.ssq_groups) * 4u : 0u, 0x00020000);
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {              // <= 256 groups: 4 per lane; a group past the count reads as zero
         const int gq = lane + 64 * q;
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
   }
   const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(w), 0, 0xffffffffu, 0x00020000);
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(x), 0, (unsigned)(T * K * 2), 0x00020000);
-  u32x4 xr[TN][4], wr[2][RW][4];
+  u32x4 xr[4][4], wr[2][RW][4];
 #pragma unroll
-  for (int t = 0; t < TN; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc)               // rows >= T are out of range of the descriptor: zeros, no fetch
       xr[t][kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, (t * K + kbase + kc * 512 + lane * 8) * 2, 0, 0);
@@ -132,13 +132,11 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
   int g = slot_w;
   if (g < ngrp) issue(std::integral_constant<int, 0>{}, g);
   // 1/rms per token from the producer's partial sums of squares (fixed order: lane-strided, then a 64-lane butterfly)
-  float inv[TN];
-#pragma unroll
-  for (int t = 0; t < TN; ++t) inv[t] = 1.f;
+  float inv[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (EPI != GV_RESID) {
     if (a.ssq_in) {
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
+      for (int t = 0; t < 4; ++t) {
         float s = ((sqv[t][0] + sqv[t][1]) + sqv[t][2]) + sqv[t][3];
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
@@ -150,11 +148,11 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
 
   auto finish = [&](auto bc, int gg) {
     constexpr int B = decltype(bc)::value;
-    float acc[RW][TN];
+    float acc[RW][4];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
+      for (int t = 0; t < 4; ++t) {
         float v = 0.f;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc)
@@ -169,14 +167,14 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-          for (int t = 0; t < TN; ++t) red[wv][r][t] = acc[r][t];
+          for (int t = 0; t < 4; ++t) red[wv][r][t] = acc[r][t];
       }
       __syncthreads();
       if (ks == 0) {
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-          for (int t = 0; t < TN; ++t) {
+          for (int t = 0; t < 4; ++t) {
             float v = red[wv][r][t];
             for (int s = 1; s < KS; ++s) v += red[wv + s][r][t];          // slice order
             acc[r][t] = v;
@@ -193,12 +191,10 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
     for (int r = 0; r < RW; ++r) {
       float v = acc[r][0];
 #pragma unroll
-      for (int tt = 1; tt < TN; ++tt) v = (tt == t) ? acc[r][tt] : v;
+      for (int tt = 1; tt < 4; ++tt) v = (tt == t) ? acc[r][tt] : v;
       val[r] = v;
     }
-    float iv = inv[0];
-#pragma unroll
-    for (int tt = 1; tt < TN; ++tt) iv = (tt == t) ? inv[tt] : iv;
+    const float iv = (t == 0) ? inv[0] : (t == 1) ? inv[1] : (t == 2) ? inv[2] : inv[3];
     const int n0 = blockIdx.x * RB + gg * RW;    // first (packed-order) output row of this pass
     if constexpr (EPI == GV_RESID) {
       // h <- round(round(gemm) + h) ; hw <- h * w_next ; sums of squares (llama.py:104,112 + the next norm's weight)
@@ -259,9 +255,9 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
   }
   if constexpr (EPI == GV_RESID) {
     // the block's sum of squares per token: waves in slot order (fixed order: deterministic)
-    if (lane < TN) sred[wv][lane] = sq_acc;
+    if (lane < 4) sred[wv][lane] = sq_acc;
     __syncthreads();
-    if (wv == 0 && lane < T && lane < TN && a.ssq_out) {
+    if (wv == 0 && lane < T && lane < 4 && a.ssq_out) {
       float s = sred[0][lane];
       for (int q = 1; q < 8; ++q) s += sred[q][lane];
       a.ssq_out[(long)lane * a.ssq_out_stride + blockIdx.x] = s;
@@ -308,14 +304,16 @@ static int gv_rows_per_block(int N, int RW, int KS) {
   return best;
 }
 
-// rows per wave and pass: K = 8192 runs as four k-slices (4 rows per pass, 2 with 8 token slots: registers); K = 2048 one
-// row per pass for the residual epilogue, a (partner) pair otherwise
-static int gv_rw(int T, int K, int epi) { return K == 8192 ? (T > 4 ? 2 : 4) : (epi == GV_RESID ? 1 : 2); }
+// rows per wave and pass: K = 8192 runs as four k-slices of 4 rows; K = 2048 one row per pass for the residual epilogue,
+// a (partner) pair otherwise
+static int gv_rw(int T, int K, int epi) { (void)T; return K == 8192 ? 4 : (epi == GV_RESID ? 1 : 2); }
 
 extern "C" int umb_gemv_ok(int T, int N, int K, int epi) {
   static const bool off = getenv("UMB_NO_GEMV") != nullptr;
-  // <= 4 rows.  An 8-slot instantiation (TN = 8) was built and measured: correct, but 1.30 vs 0.78 ms per 1B forward at
-  // T = 5 -- the 64-lane butterflies (RW x TN values per pass) and 32 activation loads per lane outweigh the MFMA kernels.
+  // <= 4 rows.  An 8-slot instantiation was built and measured: correct, but 1.30 vs 0.78 ms per 1B forward at T = 5 -- the
+  // 64-lane butterflies (rows x token slots values per pass) and 32 activation loads per lane outweigh the MFMA kernels.
+  // (Its generic form also showed a trap: per-token arrays filled in loops were promoted to LDS by hipcc, 8 KiB per block,
+  // and the q/k/v launch went from 6.2 to 19.4 us -- the kernel below keeps its four token slots in named registers.)
   if (off || T < 1 || T > 4 || (K != 2048 && K != 8192)) return 0;
   if (epi != GV_SILU && epi != GV_QKV && epi != GV_RESID) return 0;
   if (K == 8192 && epi != GV_RESID) return 0;
@@ -343,17 +341,17 @@ extern "C" int umb_gemv(void* out, const void* x, const void* w_rows, int T, int
   const int RW = gv_rw(T, K, epi);
   const int RB = gv_rows_per_block(N, RW, KS);
   if (epi == GV_RESID && a.ssq_out && a.ssq_out_stride < N / RB) return UMB_EINVAL;
-#define GV_GO(RWV, KSV, EPIV, TNV)                                                                                \
-  hipLaunchKernelGGL((gv_kernel<P, RWV, KSV, EPIV, TNV>), dim3((unsigned)(N / RB)), dim3(512), 0, st, (const u32x4*)w_rows,  \
+#define GV_GO(RWV, KSV, EPIV)                                                                                     \
+  hipLaunchKernelGGL((gv_kernel<P, RWV, KSV, EPIV>), dim3((unsigned)(N / RB)), dim3(512), 0, st, (const u32x4*)w_rows,  \
                      (const u16*)x, T, N, K, RB, a)
   DISPATCH_DTYPE(dtype, {
     if (T <= 4) {
       if (K == 2048) {
-        if (epi == GV_RESID) GV_GO(1, 1, GV_RESID, 4);
-        else if (epi == GV_SILU) GV_GO(2, 1, GV_SILU, 4);
-        else GV_GO(2, 1, GV_QKV, 4);
+        if (epi == GV_RESID) GV_GO(1, 1, GV_RESID);
+        else if (epi == GV_SILU) GV_GO(2, 1, GV_SILU);
+        else GV_GO(2, 1, GV_QKV);
       } else {
-        GV_GO(4, 4, GV_RESID, 4);
+        GV_GO(4, 4, GV_RESID);
       }
     } else {
       return UMB_EINVAL;
