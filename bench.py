@@ -149,7 +149,7 @@ class Watchdog:
                         time.sleep(3.0)         # rank 0 prints first: a worker that exits makes the launcher stop the others
                 finally:
                     sys.stdout.flush()
-                    os._exit(0)                 # the line is out: a non-zero status would only hide it from the driver
+                    os._exit(0)                 # the line is out and carries "status": "sharded phase failed: timeout ..."
 
 
 # ------------------------------------------------------------------ engines
@@ -736,6 +736,9 @@ def main():
         if printed.is_set():
             return
         printed.set()
+        # "status" is what a driver gates on: the watchdog exits 0 so that the (complete, valid) headline of this line is
+        # not lost with a hung pp / tp phase, and says so here instead of in the exit code
+        out["status"] = "ok" if not err else f"sharded phase failed: {err}"
         if err:
             out["sharded_error"] = err
             out.setdefault("pp", {"error": err})

@@ -110,7 +110,9 @@ int umb_gemm_ll(void* out, const void* x_fm, const void* wpacked, const void* me
  * issued at kernel start, a wave owns whole rows (8-row granularity: N = 2048 fills 256 CUs), v_dot2c accumulates in fp32.
  * Same reference lines and the same epilogue arithmetic as umb_gemm_ll (epi 2 / 3 / 4), with ROW-MAJOR act / hw outputs and
  * the sums of squares per workgroup: ssq_out[t][0 .. umb_gemv_groups(T, N, K)).  T <= 4; K must be 2048 (any epilogue) or 8192 (epi 4).
- * umb_gemv_ok: 1 if this (T, N, K, epi) is covered (0 with UMB_NO_GEMV=1). */
+ * umb_gemv_ok: 1 if this (T, N, K, epi) is covered (0 with UMB_NO_GEMV=1).  ssq_groups <= 256 (EINVAL beyond: four per lane).
+ * epi 3 trusts slot[t] in [0, Lmax) -- the fused epilogues are the model runtime's internal form; umb_kv_append is the
+ * range-checked stand-alone one. */
 int umb_gemv_ok(int T, int N, int K, int epi);
 int umb_gemv_groups(int T, int N, int K);
 int umb_gemv(void* out, const void* x, const void* w_rows, int T, int N, int K, int epi, const UmbGemmLL* fx, int dtype,

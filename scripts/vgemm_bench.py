@@ -1,8 +1,8 @@
 """Ablation of the register-resident verify GEMM (T = 256): each variant library (built with -DUMB_VG_*) gives WRONG
-results and only tells what its piece costs.  Usage: python scripts/r3/vg_ablate.py <lib.so> [label]"""
+results and only tells what its piece costs.  Usage: python scripts/vgemm_bench.py <lib.so> [label]"""
 import os, sys
 os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     os.environ["UMB_LIB_PATH"] = os.path.abspath(sys.argv[1])

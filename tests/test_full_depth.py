@@ -138,3 +138,138 @@ def test_70b_awq_with_1b_draft_3x4():
     r = _run_pair("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", "meta-llama/Llama-3.2-1B-Instruct",
                   torch.float16, (3, 4), None, dev)
     _assert_pair(r)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 at full depth (round 4): the reference's own 70B engine is the DYNAMIC one
+# (umbrella/speculation/dynamic_speculation_engine.py:215-327, configs/greedy_config_12gb.json, chat_config_24gb.json).
+T70 = "hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4"
+D1B = "meta-llama/Llama-3.2-1B-Instruct"
+D8BAWQ = "hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4"
+LDYN = 2048
+_cache = {}
+
+
+def _model(name, dev, **kw):
+    """one instance per (name, placement) for the whole module: a 70B-AWQ allocation is ~40 GB and ~30 s"""
+    from umbrella_amd.models import AutoModelLM
+    alloc_kw = {k: kw.pop(k) for k in ("num_cache_layers",) if k in kw}
+    key = (name, tuple(sorted(kw.items())), tuple(sorted(alloc_kw.items())))
+    if key not in _cache:
+        m = AutoModelLM.from_pretrained(name, max_length=LDYN, device=str(dev), dtype=torch.float16, **kw)
+        m.alloc(**alloc_kw)
+        _cache[key] = m
+    return _cache[key]
+
+
+def _drop(pred):
+    for k in [k for k in _cache if isinstance(k, tuple) and pred(k)]:
+        del _cache[k]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
+def _dyn_engine(target, draft, dev, graph, width, beams, depth, **knobs):
+    from umbrella_amd.speculation.dynamic_speculation_engine import DynamicSpeculationEngine
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    e = DynamicSpeculationEngine("draft", "target", dtype=torch.float16, device=str(dev), width=width, num_beams=beams,
+                                 depth=depth, max_length=LDYN, offload=False, draft_model_obj=draft, target_model_obj=target,
+                                 tokenizer=IdTokenizer(), hip_graph=graph, seed=0, **knobs)
+    e.initialize()
+    return e
+
+
+def _prompt():
+    return torch.randint(3, 128000, (96,), generator=torch.Generator().manual_seed(1)).tolist()
+
+
+def test_c3_resident_70b_awq_dynamic_w16_b24_d16():
+    """BASELINE config 3's engine with the target resident: 80 AWQ int4 layers + 16 draft layers, dynamic tree width 16 /
+    24 beams / depth 16 (T = 257: the wide verify GEMM, exact fp16 dequant), greedy.  hipGraph == eager token for token;
+    every emitted token is the arg-max of the target's own T = 1 row (skinny GEMM, folded dequant) or inside the 16-bit
+    near-tie band -- the two GEMM families are held together here at full depth."""
+    dev = torch.device("cuda:0")
+    target, draft = _model(T70, dev), _model(D1B, dev)
+    prompt, new = _prompt(), 24
+    eg = _dyn_engine(target, draft, dev, True, 16, 24, 16)
+    out_g = eg.generate(input_ids=prompt, max_new_tokens=new)
+    ee = _dyn_engine(target, draft, dev, False, 16, 24, 16)
+    out_e = ee.generate(input_ids=prompt, max_new_tokens=new)
+    tg, te = out_g["generated_tokens"], out_e["generated_tokens"]
+    assert eg.tree_size == 257 and tg == te, "hipGraph replay and eager launches disagree"
+    assert len(tg) >= new
+    exact = _check_against_ar(target, prompt, tg, TOL[torch.float16], dev, "C3 resident")
+    assert exact >= len(tg) - 3, (exact, len(tg))
+    print(dict(n=len(tg), exact=exact, accept=out_g["avg_accept_tokens"]))
+
+
+def _penalised(row, history, penalty):
+    """HF repetition penalty on the history tokens (speculation_utils.py:340-345), fp32"""
+    row = row.clone()
+    idx = torch.tensor(sorted(set(history)), device=row.device)
+    v = row[idx]
+    row[idx] = torch.where(v < 0, v * penalty, v / penalty)
+    return row
+
+
+def test_c4_70b_awq_with_8b_awq_draft_w32_b32_d24_stochastic():
+    """BASELINE config 4: 70B-AWQ target + 8B-AWQ draft (32 int4 layers), dynamic width 32 / 32 beams / depth 24
+    (T = 769), stochastic verification (temperature 0.6, top-p 0.9, top-k 32, repetition penalty 1.05).  One seed:
+    hipGraph == eager draw for draw; every sampled token lies inside the top-k support of the target's own
+    penalised T = 1 row (teacher forced), within the 16-bit band at the k-th logit."""
+    dev = torch.device("cuda:0")
+    target, draft = _model(T70, dev), _model(D8BAWQ, dev)
+    knobs = dict(temperature=0.6, topp=0.9, topk=32, repetition_penalty=1.05)
+    prompt, new = _prompt(), 12
+    eg = _dyn_engine(target, draft, dev, True, 32, 32, 24, **knobs)
+    out_g = eg.generate(input_ids=prompt, max_new_tokens=new)
+    ee = _dyn_engine(target, draft, dev, False, 32, 32, 24, **knobs)
+    out_e = ee.generate(input_ids=prompt, max_new_tokens=new)
+    tg, te = out_g["generated_tokens"], out_e["generated_tokens"]
+    assert eg.tree_size == 769 and tg == te, "hipGraph replay and eager launches disagree under one seed"
+    assert len(tg) >= new
+    tol = TOL[torch.float16]
+    target.clear()
+    row = target.prefill_tokens(torch.tensor(prompt, dtype=torch.int32, device=dev), 0)
+    # token 0 is the plain arg-max of the prompt's last row with EOS masked (dynamic:130); the rest are sampled
+    r0 = row.clone()
+    r0[list(target.eos_tokens)] = -float("inf")
+    assert float(r0.max() - r0[tg[0]]) < 2 * tol
+    for i in range(1, len(tg)):
+        row = target.prefill_tokens(torch.tensor([tg[i - 1]], dtype=torch.int32, device=dev), len(prompt) + i - 1)
+        pen = _penalised(row, prompt + tg[:i], 1.05)
+        kth = float(pen.topk(32).values[-1])
+        assert float(pen[tg[i]]) >= kth - 2 * tol, f"token {i} = {tg[i]} is outside the top-32 support of its row"
+    target.clear()
+    print(dict(n=len(tg), accept=out_g["avg_accept_tokens"]))
+    _drop(lambda k: k[0] == D8BAWQ)
+
+
+@pytest.mark.parametrize("ncl", [0, 40])
+def test_c3_offloaded_equals_resident(ncl):
+    """BASELINE config 3 proper: the 70B-AWQ target's layers streamed from pinned host DRAM (all 80, and 40 behind a
+    40-layer resident prefix with the 8-slab device ring), 1B draft, dynamic w16/b24/d16, greedy: the tokens, the accept
+    lengths and the bonus tokens of every iteration equal the resident target's, token for token."""
+    dev = torch.device("cuda:0")
+    prompt, iters = _prompt(), 4
+
+    def run(target):
+        eng = _dyn_engine(target, _model(D1B, dev), dev, True, 16, 24, 16)
+        assert eng._prefill(torch.tensor([prompt]))
+        start, trace = eng.num_nodes, []
+        for _ in range(iters):
+            eng.step()
+            trace.append((eng.num_nodes, eng.last_accept, eng.last_bonus))
+        out = (trace, eng.tokens[start:eng.num_nodes + 1].tolist())
+        eng.reset()
+        return out
+
+    if "resident_trace" not in _cache:
+        _cache["resident_trace"] = run(_model(T70, dev))
+    _drop(lambda k: k[0] == T70)                                # the resident copy makes room for the slab ring
+    target = _model(T70, dev, offload=True, num_cache_layers=ncl)
+    assert sum(1 for h in target.host_slabs if h is not None) == 80 - ncl
+    assert target.n_slabs == (2 if ncl == 0 else 8)
+    got = run(target)
+    _drop(lambda k: k[0] == T70)                                # releases the pinned host slabs as well
+    assert got == _cache["resident_trace"]

@@ -196,6 +196,10 @@ def _draft_logits(dev, gemv, T, dtype, layers=4):
     finally:
         os.environ.pop("UMB_GEMV", None)
     assert (getattr(m.layers[0]["qkv"], "w_rows", None) is not None) == gemv
+    assert m._layer_structs[0].qkv.w_rows is None, "GEMV is opt-in: a freshly allocated model publishes no row-major copies"
+    if gemv:
+        m.use_gemv(True)                    # the engines do this for their draft
+        assert m._layer_structs[0].qkv.w_rows and m._layer_structs[3].down.w_rows
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(3, 128000, (40 + T,), generator=g, dtype=torch.int32).to(dev)
     m.prefill_tokens(ids[:40], 0)
@@ -219,3 +223,43 @@ def test_gemv_schedule_model_logits_match_lowlat_schedule(dev, dtype, T):
     top2 = b.topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
     assert torch.equal(a.argmax(-1)[clear], b.argmax(-1)[clear])
+
+
+def test_gemv_is_a_draft_role_only(dev):
+    """a target of Llama-3.2-1B shapes (K = 2048 / 8192: the shapes the GEMV family serves) must keep ONE kernel
+    path for every T <= 64, or its T = 1 (autoregressive) and T = 13 (tree verify) logits of the same token differ and
+    greedy spec != greedy AR at near-ties.  The engines flag roles: draft -> GEMV on, target -> off; the target's row of
+    a 1-row forward is then bit-identical to the same token's row in a 3-row forward."""
+    import copy
+    import os
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.models.llama import Llama
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    os.environ["UMBRELLA_SYNTHETIC"] = "1"
+    cfg = copy.copy(KNOWN["meta-llama/Llama-3.2-1B-Instruct"])
+    cfg.num_hidden_layers = 2
+    dtype = torch.float16
+    mk = lambda seed, **kw: Llama("meta-llama/Llama-3.2-1B-Instruct", max_length=256, device=dev, dtype=dtype, config=cfg,
+                                  seed=seed, **kw)
+    target, draft = mk(1), mk(2, cuda_graph=True)
+    target.alloc(); draft.alloc()
+    eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap=generate_sequoia_tree(3, 4), max_length=256,
+                                  draft_model_obj=draft, target_model_obj=target, tokenizer=IdTokenizer())
+    eng.initialize()
+    assert target._layer_structs[0].qkv.w_rows is None and target._layer_structs[1].down.w_rows is None
+    assert draft._layer_structs[0].qkv.w_rows and draft._layer_structs[1].down.w_rows
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 128000, (43,), generator=g, dtype=torch.int32).to(dev)
+    pre = torch.tensor([40], dtype=torch.int32, device=dev)
+    rows = {}
+    for T in (1, 3):
+        target.clear()
+        target.prefill_tokens(ids[:40], 0)
+        pos = torch.arange(40, 40 + T, dtype=torch.int32, device=dev)
+        target.forward_explicit(ids[40:40 + T].contiguous(), pos, pos, pre, head_from=0)
+        rows[T] = target.logits_buffer[0].clone()
+    assert torch.equal(rows[1], rows[3]), "a target's logits must not depend on the rows sharing its launch"
+    out = eng.generate(input_ids=ids[:40].tolist(), max_new_tokens=16)
+    assert len(out["generated_tokens"]) >= 16

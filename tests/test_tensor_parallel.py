@@ -324,3 +324,100 @@ def test_tp_rccl_hook_inside_the_iteration_graph(dev):
                 assert calls == []
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ the real 70B shard shapes (round 4)
+class _ThreadComm:
+    """TPComm face for P ranks living as THREADS of one process on one GPU: the all-reduce of the native layer chain's
+    hook is a barrier + an fp32 sum over the ranks' partial buffers in rank order (what a reduce over the links
+    computes), the vocabulary all-gather a barrier + concatenation.  Host-staged semantics (no hipGraph)."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self.sh = rank, world, shared
+        self.live, self.backend, self.staged = True, "threads", True
+
+    def _meet(self):
+        torch.cuda.current_stream().synchronize()
+        self.sh["barrier"].wait(timeout=300)
+
+    def all_reduce(self, t):
+        self.sh["slot"][self.rank] = t
+        self._meet()
+        total = self.sh["slot"][0].clone()
+        for r in range(1, self.world):
+            total += self.sh["slot"][r]
+        self._meet()                                    # every rank has read every buffer
+        t.copy_(total)
+
+    def all_gather_columns(self, local, full, scratch=None):
+        self.sh["cols"][self.rank] = local
+        self._meet()
+        full.copy_(torch.cat([self.sh["cols"][r] for r in range(self.world)], dim=1))
+        self._meet()
+
+
+@pytest.mark.gpu
+def test_tp8_shards_of_the_70b_awq_on_one_gpu(dev):
+    """All EIGHT ranks of a tensor-parallel Llama-3.1-70B-AWQ (2 of its 80 layers, real widths) as threads on one GPU:
+    the int4 shard shapes TP 8 creates -- q/k/v N 1280 x K 8192, o N 8192 x K 1024, gate/up N 7168 x K 8192, down
+    N 8192 x K 3584, a 16 032-column lm_head slice -- run through umb_model_forward_tp at T = 13 (skinny split-K kernels,
+    4 un-summed slabs into the hook) and T = 257 (wide verify kernels, slabs summed before the hook); the all-gathered
+    logits equal the unsharded model's up to fp32 summation order / 16-bit rounding of the residual stream."""
+    import copy
+    import threading
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.models.llama import Llama
+    from umbrella_amd.tensor_parallel import LazySyntheticShard, TensorParallelLlama, local_config
+    dtype, world, L, Lmax = torch.float16, 8, 2, 512
+    cfg = copy.copy(KNOWN["hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4"])
+    cfg.num_hidden_layers = L
+    lc = local_config(cfg, world)
+    assert (lc.num_attention_heads, lc.num_key_value_heads, lc.intermediate_size, lc.vocab_size) == (8, 1, 3584, 16032)
+    full = Llama("tp-ref", max_length=Lmax, device=str(dev), dtype=dtype, config=cfg, sched="split",
+                 state_dict=LazySyntheticShard(cfg, 0, 1, str(dev), dtype, seed=3))
+    full.alloc()
+    full.reserve(272, logit_rows=272)
+    shared = {"barrier": threading.Barrier(world), "slot": [None] * world, "cols": [None] * world}
+    tps = []
+    for r in range(world):
+        tp = TensorParallelLlama.build(cfg, LazySyntheticShard(cfg, r, world, str(dev), dtype, seed=3),
+                                       _ThreadComm(r, world, shared), Lmax, str(dev), dtype)
+        tp.reserve(272, logit_rows=272)
+        tps.append(tp)
+    shapes = {k: (v.N, v.K, v.awq) for k, v in tps[0].m.layers[0].items()}
+    assert shapes == {"qkv": (1280, 8192, 1), "o": (8192, 1024, 1), "gu": (7168, 8192, 1), "down": (8192, 3584, 1)}, shapes
+    assert tps[0].m.lm_head.N == 16032
+    gen = torch.Generator().manual_seed(5)
+    for T, tol in ((13, 0.05), (257, 0.05)):
+        ids = torch.randint(3, 128000, (T,), generator=gen).int().to(dev)
+        pos = torch.arange(T, dtype=torch.int32, device=dev)
+        pre = torch.zeros(1, dtype=torch.int32, device=dev)
+        full.clear()
+        full.forward_explicit(ids, pos, pos, pre, head_from=0)
+        ref = full.logits_buffer[:T].clone()
+        errs = []
+
+        def work(tp):
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    tp.clear()
+                    tp.forward_explicit(ids, pos, pos, pre, head_from=0)
+                    torch.cuda.current_stream().synchronize()
+            except Exception as e:                                  # a dead rank must not leave the others at the barrier
+                errs.append(e)
+                shared["barrier"].abort()
+        torch.cuda.synchronize()
+        th = [threading.Thread(target=work, args=(tp,)) for tp in tps]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not errs, errs
+        assert not any(t.is_alive() for t in th)
+        scale = float(ref.abs().max())
+        for tp in tps:                                              # every rank holds the same gathered logits
+            d = float((tp.logits_buffer[:T] - ref).abs().max())
+            assert d < tol * max(scale, 1.0), (T, tp.rank, d, scale)
+        assert torch.equal(tps[0].logits_buffer[:T], tps[7].logits_buffer[:T])
+        assert torch.equal(tps[0].logits_buffer[:T].argmax(-1), ref.argmax(-1)) or \
+            float((ref.max(-1).values - ref.gather(1, tps[0].logits_buffer[:T].argmax(-1, keepdim=True))[:, 0]).max()) < 2 * tol

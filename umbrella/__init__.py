@@ -53,5 +53,7 @@ def __getattr__(name):
         pass
     try:
         return importlib.import_module(_PREFIX + name)
-    except ImportError:                                     # hasattr / inspect.unwrap / mock.patch probe with AttributeError
+    except ModuleNotFoundError as e:                        # hasattr / inspect.unwrap / mock.patch probe with AttributeError
+        if e.name not in (_PREFIX + name, _TARGET + name):
+            raise                                           # the submodule exists and ITS import failed: a real error
         raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None

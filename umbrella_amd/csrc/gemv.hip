@@ -229,6 +229,9 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
           const float sl_ = P::to_f(er[B].sl[r / 2]), sh = P::to_f(er[B].sh[r / 2]);
           const float lo0 = rnd<P>(mul_rnd<P>(a0, cl) + mul_rnd<P>(-b0, sl_));
           const float hi0 = rnd<P>(mul_rnd<P>(b0, ch) + mul_rnd<P>(a0, sh));
+          // slot_t is trusted here (the model runtime derives it from the engine's guarded state: HipEngine.step refuses
+          // a tree that would pass max_length); a per-store range check costs this kernel 24 B of scratch per lane
+          // (tests/test_abi.py guards that).  The stand-alone umb_kv_append is the range-checked form.
           u16* dst = (head < a.Hq) ? a.q_out + ((long)t * a.Hq + head) * D : a.kc + ((long)(head - a.Hq) * a.Lmax + slot_t) * D;
           dst[m] = P::from_f(lo0);
           dst[m + half] = P::from_f(hi0);
@@ -336,7 +339,8 @@ extern "C" int umb_gemv(void* out, const void* x, const void* w_rows, int T, int
   if (epi == GV_RESID && (!a.h || (a.norm_w && !a.hw))) return UMB_EINVAL;
   if (epi == GV_SILU && (!out || N % 2)) return UMB_EINVAL;
   if (epi == GV_QKV && (!a.pos || !a.slot || !a.cosT || !a.sinT || !a.q_out || !a.kc || !a.vt || a.D % 2 || N % 2)) return UMB_EINVAL;
-  if (a.ssq_in && (a.ssq_groups < 1 || a.ssq_dim <= 0.f)) return UMB_EINVAL;
+  // the kernel reads the producer's sums of squares as <= 4 values per lane: 256 groups at most
+  if (a.ssq_in && (a.ssq_groups < 1 || a.ssq_groups > 256 || a.ssq_dim <= 0.f)) return UMB_EINVAL;
   const int KS = K / 2048;
   const int RW = gv_rw(T, K, epi);
   const int RB = gv_rows_per_block(N, RW, KS);

@@ -250,7 +250,11 @@ static int head_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
 static inline bool use_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s) {
   if (ws->fused != 2 || s->T > 4 || s->layer_begin >= s->layer_end) return false;
   const UmbLayer& ly = m->layers[s->layer_begin];
-  if (!ly.qkv.w_rows || !ly.o.w_rows || !ly.gu.w_rows || !ly.down.w_rows || m->H % 64) return false;
+  for (int l = s->layer_begin; l < s->layer_end; ++l) {              // every layer of the range, not only its first
+    const UmbLayer& x = m->layers[l];
+    if (!x.qkv.w_rows || !x.o.w_rows || !x.gu.w_rows || !x.down.w_rows) return false;
+  }
+  if (m->H % 64) return false;
   if (!umb_gemv_ok(s->T, ly.qkv.N, ly.qkv.K, 3) || !umb_gemv_ok(s->T, ly.o.N, ly.o.K, 4) ||
       !umb_gemv_ok(s->T, ly.gu.N, ly.gu.K, 2) || !umb_gemv_ok(s->T, ly.down.N, ly.down.K, 4)) return false;
   const int og = umb_gemv_groups(s->T, ly.o.N, ly.o.K), dg = umb_gemv_groups(s->T, ly.down.N, ly.down.K);

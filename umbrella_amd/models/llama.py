@@ -102,8 +102,11 @@ class PackedLinear:
         s.w = self.w.data_ptr() if w_ptr is None else w_ptr
         s.meta = (self.meta.data_ptr() if self.meta is not None else 0) if meta_ptr is None else meta_ptr
         s.N, s.K, s.awq, s.R, s.S, s.tb, s.S_row = self.N, self.K, self.awq, self.R, self.S, self.tb, self.S_row
-        rows = getattr(self, "w_rows", None)          # row-major copy for the GEMV family (resident dense layers only)
-        s.w_rows = rows.data_ptr() if (rows is not None and w_ptr is None) else 0
+        # row-major copy for the GEMV family (resident dense layers only).  The pointer is published only while the model
+        # is flagged as a DRAFT (Llama.use_gemv): GEMV and MFMA kernels sum in different orders, so a model whose
+        # T = 1 and T = 13 forwards must agree bit for bit (every target: greedy spec == greedy AR) never takes them.
+        rows = getattr(self, "w_rows", None)
+        s.w_rows = rows.data_ptr() if (rows is not None and w_ptr is None and getattr(self, "gemv_on", False)) else 0
         return s
 
     def apply_silu(self, x: torch.Tensor) -> torch.Tensor:
@@ -447,6 +450,20 @@ class Llama(LLMBase):
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ workspace
+    def use_gemv(self, on: bool):
+        """Draft role switch (engines call it; default off).  on: forwards of <= 4 rows run on the row-streaming GEMV
+        kernels (csrc/gemv.hip) wherever alloc() kept row-major weight copies; off: every T <= 64 forward of this
+        model takes ONE shape-only kernel path, which is what makes a token's logits independent of how many rows
+        share its launch (the batch invariance greedy spec == greedy AR rests on).  Changes launch arguments: call
+        before any graph capture."""
+        for i, lins in enumerate(self.layers):
+            for key, ln in lins.items():
+                ln.gemv_on = bool(on)
+                rows = getattr(ln, "w_rows", None)
+                streamed = self.host_slabs[i] is not None
+                getattr(self._layer_structs[i], key).w_rows = rows.data_ptr() if (on and rows is not None and not streamed) else 0
+        self.gemv = bool(on)
+
     def reserve(self, tokens: int, logit_rows: int | None = None):
         """Size the activation workspace for forwards of up to `tokens` rows (`logit_rows` of which may go through the
         lm_head; default all).  Re-allocates: call before any graph capture."""

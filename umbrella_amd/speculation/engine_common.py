@@ -67,6 +67,12 @@ class HipEngine(BaseEngine):
             self.target_model.alloc(**dict(cfg))
         else:
             self.target_model = self._target_model
+        # roles: the draft may take the <= 4-row GEMV kernels (its logits only steer proposals); the target keeps one
+        # kernel path per shape so that a token's logits never depend on the rows sharing its launch
+        if self.draft_model is not self.target_model:
+            for mdl, on in ((self.target_model, False), (self.draft_model, True)):
+                if hasattr(mdl, "use_gemv"):
+                    mdl.use_gemv(on)
         self.max_length = self.target_model.max_length
         assert self.draft_model.max_length == self.max_length
         assert self.draft_model.config.vocab_size == self.target_model.config.vocab_size

@@ -220,6 +220,7 @@ class TensorParallelLlama:
         sd = dict(shard_state_dict(source, cfg, comm.rank, comm.world)) if isinstance(source, dict) else source
         m = Llama(f"{name}-tp{comm.rank}of{comm.world}", max_length=max_length, device=device, dtype=dtype, state_dict=sd,
                   config=lc, seed=seed, sched="split")
+        m.fused = False          # umb_model_forward_tp runs the 8-launch schedule only: UMB_FUSED=1 in the environment must not reach a shard
         m.alloc()
         return cls(cfg, m, comm, force_hook=force_hook)
 
@@ -250,22 +251,42 @@ class TensorParallelLlama:
     def logit_rows(self):
         return self.m.logit_rows
 
+    def _raise_hook_error(self):
+        """A Python exception inside the all-reduce hook reaches the C chain as rc = 1 (the forward aborts with -5 on this
+        rank while its peers wait inside the collective): surface the cause at once and take the group down with it
+        instead of leaving the peers to hang until their own timeout."""
+        if self._err is None:
+            return
+        e, self._err = self._err, None
+        try:
+            if self.comm.live and self.world > 1:
+                import torch.distributed as dist
+                dist.destroy_process_group(self.comm.group) if self.comm.group is not None else dist.destroy_process_group()
+        except Exception:
+            pass
+        raise e
+
+    def _guarded(self, fn, *a, **kw):
+        try:
+            fn(*a, **kw)
+        except RuntimeError:
+            self._raise_hook_error()                         # the hook's own exception, not "umb_model_forward failed: -5"
+            raise
+        self._raise_hook_error()
+
     def _gather(self, rows):
-        if self._err is not None:
-            e, self._err = self._err, None
-            raise e
         if rows > 0:
             self.comm.all_gather_columns(self.m._bufs["logits"][:rows], self._full[:rows], self._scratch)
 
     # ---- the model-runtime face
     def forward_tree(self, tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=0, **kw):
-        self.m.forward_tree(tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=head_from, **kw)
+        self._guarded(self.m.forward_tree, tokens_all, n_ptr, depth, tree_off, T, mask_bits, mask_words, head_from=head_from, **kw)
         self._gather(T - head_from)
 
     def forward_explicit(self, tokens, positions, slots, prefix_len, mask_bits=None, mask_words=0, n_mask_keys=None,
                          head_from=0, **kw):
-        self.m.forward_explicit(tokens, positions, slots, prefix_len, mask_bits=mask_bits, mask_words=mask_words,
-                                n_mask_keys=n_mask_keys, head_from=head_from, **kw)
+        self._guarded(self.m.forward_explicit, tokens, positions, slots, prefix_len, mask_bits=mask_bits,
+                      mask_words=mask_words, n_mask_keys=n_mask_keys, head_from=head_from, **kw)
         self._gather(tokens.shape[0] - head_from)
 
     @torch.inference_mode()
