@@ -24,6 +24,8 @@ for name, N, K, il in (("qkv", 10240, 8192, 0), ("o", 8192, 8192, 0), ("gu", 573
     lins = [PackedLinear.from_awq(*synth_awq_tensors(N, K, 128, dev, gen), interleave=bool(il)) for _ in range(ncopy)]
     S = lib.umb_gemm_wide_split(T, N, lins[0].S)
     x = torch.randn(T, K, device=dev).to(torch.float16)
+    if os.environ.get("XZERO"):          # DVFS probe: zero activations (the chip clocks to its power budget: MI355X_MICROARCH.md)
+        x.zero_()
     out = torch.empty(max(S * T * N, 1), dtype=torch.float32, device=dev)
     epi = 2 if il else 0
     def launch(i):

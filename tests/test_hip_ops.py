@@ -683,6 +683,53 @@ def test_verify_gemm_wide_full_width(dev, awq, T):
     assert float((y[:, :128] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("T", [256, 257, 385, 769])
+@pytest.mark.parametrize("shape", ["qkv", "gu", "down"])
+def test_verify_gemm_wide_every_output_70b_shapes(dev, shape, T):
+    """The int4 verify GEMM at the real 70B layer shapes (two-phase kernels: 128-token items, 144-token items for
+    T = w d + 1, every split count): EVERY output -- all T rows, all N columns, every K split summed -- against an fp32
+    matmul over the exactly dequantised fp16 weights W = fp16((q - z) s) (awq_ext.dequantize_weights_cuda's values,
+    awq_utils.py:67-77); the only difference allowed is fp32 summation order.  gate/up runs its fused SiLU(gate) * up
+    epilogue (llama.py:107-110) and is compared after the same roundings."""
+    from test_hip_engine import _awq_dequant_torch
+    from umbrella_amd.models.llama import PackedLinear
+    from umbrella_amd.models.synthetic import synth_awq_tensors
+    N, K, il = {"qkv": (10240, 8192, False), "gu": (2 * 28672, 8192, True), "down": (8192, 28672, False)}[shape]
+    if shape == "gu" and T == 385:
+        pytest.skip("covered by 257 / 769 (same kernel instantiation)")
+    gen = torch.Generator(device=dev).manual_seed(T + N)
+    qw, qz, sc = synth_awq_tensors(N, K, 128, dev, gen)
+    lin = PackedLinear.from_awq(qw, qz, sc, interleave=il)
+    x = (torch.randn(T, K, device=dev, generator=gen) * 0.5).half()
+    wd = _awq_dequant_torch(qw, qz, sc).float()                       # [K, N], exact fp16 values
+    ref = x.float() @ wd
+    del wd
+    if il:
+        act = lin.apply_silu(x)
+        I = N // 2
+        gate, up = ref[:, :I].half(), ref[:, I:].half()
+        want = (torch.nn.functional.silu(gate.float()).half().float() * up.float())
+        err = (act.float() - want).abs().max()
+        assert float(err) <= 8 * torch.finfo(torch.float16).eps * float(want.abs().max()), float(err)
+        # and no output may be off by more than a rounding step of its own magnitude (a misplaced row / token would be)
+        bad = ((act.float() - want).abs() > 4e-3 * want.abs() + 1e-4 * float(want.abs().max())).sum()
+        assert int(bad) == 0, int(bad)
+    else:
+        S = _lib_wide_split(T, N, lin.S)
+        part = torch.empty(S, T, N, dtype=torch.float32, device=dev)
+        from umbrella_amd import _lib
+        _lib.call("umb_gemm", part, x, x.stride(0), lin.w, lin.meta, T, N, K, 1, S, lin.Rtb, 0, _lib.dtype_code(x.dtype))
+        y = part.sum(0)
+        scale = float(ref.abs().max())
+        err = float((y - ref).abs().max())
+        assert err <= 2e-4 * scale, (err, scale)
+
+
+def _lib_wide_split(T, N, S):
+    from umbrella_amd import _lib
+    return _lib.load().umb_gemm_wide_split(T, N, S)
+
+
 # ------------------------------------------------------------------ stand-alone 16-bit RoPE / KV append / slab copy (C-ABI completeness)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("layout", [0, 1])
