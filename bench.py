@@ -758,6 +758,10 @@ def main():
                 r = getattr(importlib.import_module(mod), fn)(sargs, wl, dtype, device, rank, world)
                 if rank == 0:
                     out[name] = r
+                    # a mis-bound launch (several ranks on one physical device) must not pass for an N-GPU measurement
+                    if r and not share_gpu() and r.get("n_distinct_devices") != world:
+                        out[name]["error"] = (f"{r.get('n_distinct_devices')} distinct devices behind {world} ranks: "
+                                              "not an N-GPU measurement")
             except Exception as e:      # an exception on one rank may leave the others in a collective: the watchdog ends them
                 import traceback
                 traceback.print_exc()

@@ -24,6 +24,7 @@ SHAPES = {"70b": (torch.float16, 13, [("qkv", 10240, 8192, 1, 0), ("o", 8192, 81
           "bal": (torch.float16, 13, [("gu", 57344, 8192, 1, 1), ("gu", 65536, 8192, 1, 1), ("gu", 49152, 8192, 1, 1)]),
           # fixed cost vs streaming slope: the same N at three K
           "kscan": (torch.float16, 13, [("gu", 57344, 512, 1, 1), ("gu", 57344, 1024, 1, 1), ("gu", 57344, 2048, 1, 1), ("gu", 57344, 4096, 1, 1), ("gu", 57344, 8192, 1, 1), ("gu", 57344, 16384, 1, 1)]),
+          "8bawq": (torch.float16, 32, [("qkv", 6144, 4096, 1, 0), ("o", 4096, 4096, 1, 0), ("gu", 28672, 4096, 1, 1), ("down", 4096, 14336, 1, 0)]),
           "8b": (torch.bfloat16, 31, [("qkv", 6144, 4096, 0, 0), ("o", 4096, 4096, 0, 0), ("gu", 28672, 4096, 0, 1), ("down", 4096, 14336, 0, 0)])}
 
 
@@ -118,6 +119,7 @@ def bench_forward(name, layers, T, dtype):
         cfg.num_hidden_layers = layers
         m = Llama(name, max_length=2048, device=dev, dtype=dtype, config=cfg)
         m.alloc()
+        m.use_gemv(os.environ.get("GEMV", "1") != "0")         # draft role (<= 4-row forwards on the GEMV family where it exists)
         ids = torch.randint(3, 128000, (128 + T,), dtype=torch.int32, device=dev)
         m.prefill_tokens(ids[:128], 0)
         step = ids[128:].contiguous()
@@ -230,6 +232,9 @@ for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
             bench_forward("meta-llama/Llama-3.2-1B-Instruct", 16, T, torch.float16)
     elif what == "fwd70b":
         bench_forward("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", 16, int(os.environ.get("T70", 13)), torch.float16)
+    elif what == "fwd8bawq":
+        for T in (int(v) for v in os.environ.get("T8B", "1,2,32").split(",")):
+            bench_forward("hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4", 32, T, torch.float16)
     elif what == "fwd8b":
         for T in (int(v) for v in os.environ.get("T8B", "31").split(",")):
             bench_forward("meta-llama/Llama-3.1-8B-Instruct", 32, T, torch.bfloat16)

@@ -65,3 +65,10 @@ def test_gpus2_shared_gpu_runs_replicas_pp_and_tp():
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert out["pp"].get("n_ranks_rccl") == 2 and out["pp"]["ms_per_step"] > 0, out["pp"]
     assert out["tp"].get("n_ranks_rccl") == 2 and out["tp"]["ms_per_step"] > 0, out["tp"]
+    # round 4: the sharded legs run under the headline's acceptance knob (same acc vector and seed), so their
+    # ms_per_step / accept_len compare with the N = 1 line; the device census sees that both ranks share ONE device here
+    for leg in ("pp", "tp"):
+        assert out[leg]["accept_len"] > 1.5 and out[leg]["acc"] == out["config"]["acc"], out[leg]
+        assert out[leg]["n_distinct_devices"] == 1 and len(out[leg]["devices"]) == 1, out[leg]
+        assert out[leg]["oracle_draft_divergence"] == 0
+    assert "hop_us" in out["pp"] and "allreduce_us" in out["tp"] and out["status"] == "ok"

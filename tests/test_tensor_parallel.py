@@ -341,6 +341,7 @@ class _ThreadComm:
         self.sh["barrier"].wait(timeout=300)
 
     def all_reduce(self, t):
+        self.sh.setdefault("numel", set()).add(t.numel())
         self.sh["slot"][self.rank] = t
         self._meet()
         total = self.sh["slot"][0].clone()
@@ -360,8 +361,8 @@ class _ThreadComm:
 def test_tp8_shards_of_the_70b_awq_on_one_gpu(dev):
     """All EIGHT ranks of a tensor-parallel Llama-3.1-70B-AWQ (2 of its 80 layers, real widths) as threads on one GPU:
     the int4 shard shapes TP 8 creates -- q/k/v N 1280 x K 8192, o N 8192 x K 1024, gate/up N 7168 x K 8192, down
-    N 8192 x K 3584, a 16 032-column lm_head slice -- run through umb_model_forward_tp at T = 13 (skinny split-K kernels,
-    4 un-summed slabs into the hook) and T = 257 (wide verify kernels, slabs summed before the hook); the all-gathered
+    N 8192 x K 3584, a 16 032-column lm_head slice -- run through umb_model_forward_tp at T = 13 (skinny split-K kernels)
+    and T = 257 (wide verify kernels); the hook always receives ONE summed [T, H] fp32 tile (T H 4 bytes); the all-gathered
     logits equal the unsharded model's up to fp32 summation order / 16-bit rounding of the residual stream."""
     import copy
     import threading
@@ -414,6 +415,7 @@ def test_tp8_shards_of_the_70b_awq_on_one_gpu(dev):
             t.join(timeout=600)
         assert not errs, errs
         assert not any(t.is_alive() for t in th)
+        assert shared.pop("numel") == {T * cfg.hidden_size}, "the collective carries one [T, H] fp32 tile, never the split-K slabs"
         scale = float(ref.abs().max())
         for tp in tps:                                              # every rank holds the same gathered logits
             d = float((tp.logits_buffer[:T] - ref).abs().max())

@@ -62,16 +62,18 @@ static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
 // ---- tensor parallelism: this rank holds 1/P of every linear (q/k/v, gate/up column-split; o, down
 // row-split), so the fp32 partial sums of the two row-split GEMMs are summed over the ranks before the residual reduce.
 // The collective is the caller's (RCCL all-reduce on `st`, captured into the iteration's hipGraph like every kernel
-// here; host-staged gloo in the CPU-side tests): two calls per layer.  Small tiles (<= 2 MiB: the T <= 64 verify) go
-// out with their split-K slabs as they are -- no extra kernel --, larger ones are summed over the splits first.
+// here; host-staged gloo in the CPU-side tests): two calls per layer.  The split-K slabs are ALWAYS summed first
+// (umb_sum_splits, one ~5 us launch): the collective then carries exactly one [T, H] fp32 tile -- T H 4 bytes, 426 KB at
+// T = 13 -- instead of S of them (round 3 sent the four slabs of a T = 13 tile as they were: 1.7 MB per call, 160 calls per
+// 70B verify, on point-to-point links where such messages are latency- and per-link-bound).
 static inline bool tp_on(const UmbTP* tp) { return tp && tp->world > 1 && tp->allreduce; }
 static int tp_allreduce(const UmbTP* tp, float* partial, int* S, long TN, hipStream_t st) {
   if (!tp_on(tp)) return UMB_OK;
-  if ((long)*S * TN * 4 > (2l << 20) && *S > 1) {
+  if (*S > 1) {
     CK(umb_sum_splits(partial, *S, TN, st));
     *S = 1;
   }
-  return tp->allreduce(tp->ctx, partial, (int64_t)*S * TN, st) ? UMB_EHIP : UMB_OK;
+  return tp->allreduce(tp->ctx, partial, (int64_t)TN, st) ? UMB_EHIP : UMB_OK;
 }
 
 // Schedule 0 (default): one decoder layer = 8 launches; split-K partials are reduced at kernel boundaries by

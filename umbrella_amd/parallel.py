@@ -413,40 +413,68 @@ def shutdown_pipeline(eng):
     eng._comm.plan(OP_STOP)
 
 
+def hop_probe(device, nbytes, reps=30):
+    """One isolated hop of the verify pipeline: a [T, H] 16-bit activation sent rank 0 -> rank 1 and back, `reps` round
+    trips behind one warm-up; -> microseconds per one-way hop (None in a 1-rank group).  Collective over ranks 0 and 1."""
+    import time
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world < 2:
+        return None
+    staged = dist.get_backend() == "gloo"
+    buf = torch.zeros(max(nbytes // 2, 1), dtype=torch.float16, device="cpu" if staged else device)
+    dist.barrier()
+    if rank > 1:
+        dist.barrier()
+        return None
+    us = None
+    for timed in (False, True):
+        if not staged:
+            torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(reps if timed else 3):
+            if rank == 0:
+                dist.send(buf, 1); dist.recv(buf, 1)
+            else:
+                dist.recv(buf, 0); dist.send(buf, 0)
+        if not staged:
+            torch.cuda.synchronize()
+        us = (time.time() - t0) / reps / 2 * 1e6
+    dist.barrier()
+    return round(us, 2)
+
+
 def pp_measure(args, wl, dtype, device, rank, world):
     """One request, the target's layers sharded over the ranks of the default process group (static 3x4, greedy; BASELINE
     config 5): rank 0 drives and returns the result dict, the other ranks serve stage forwards inside this call and
-    return None.  Collective: every rank of the group must call it.  Nothing is printed, the group stays up."""
-    import time
-
+    return None.  Collective: every rank of the group must call it.  Nothing is printed, the group stays up.
+    The acceptance knob is the headline's (same acc vector, same seed: speculation/steering.py), so `ms_per_step` /
+    `accept_len` compare 1 : 1 with the N = 1 line; `hop_us` = one isolated [T, H] send/recv hop, `devices` = the
+    physical device identities gathered over the group."""
     import __graft_entry__ as ge
-    from .sequoia_utils import generate_sequoia_tree
+    from .models.config import KNOWN
+    from .sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from .speculation.steering import device_census, steered_measure
     ge.build()
+    census = device_census(device, dist)
+    gm = generate_sequoia_tree(3, 4)
+    hop_bytes = gm["size"] * KNOWN[wl["target"]].hidden_size * 2
+    hop_us = hop_probe(device, hop_bytes)
     eng = build_pipelined_engine(device, dtype=dtype, seed=args.seed, model=wl["target"], draft_model=wl["draft"],
-                                 growmap=generate_sequoia_tree(3, 4), max_length=args.max_length, exit_layer=16)
+                                 growmap=gm, max_length=args.max_length, exit_layer=16)
     if eng is None:
         return None
     g = torch.Generator().manual_seed(1234)
     prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)
-    assert eng._prefill(prompt)
-    for _ in range(args.warmup):
-        eng.step()
-    torch.cuda.synchronize()
-    start = eng.num_nodes
-    t0 = time.time()
-    for _ in range(args.steps):
-        eng.step()
-    torch.cuda.synchronize()
-    dt = time.time() - t0
-    tokens = eng.num_nodes - start
+    acc = list(DEFAULT_ACC)
+    r = steered_measure(eng, prompt, acc, args.seed, args.warmup, args.steps, len(gm["roots"]))
     layers = [hi - lo for lo, hi in split_layers(eng._stage_model.config.num_hidden_layers, world)]
     shutdown_pipeline(eng)
-    hop_bytes = eng.tree_size * eng._stage_model.config.hidden_size * 2
-    return {"ms_per_step": round(dt / args.steps * 1e3, 4), "tokens_per_s_raw_draft": round(tokens / dt, 2),
-            "accept_len_raw_draft": round(tokens / args.steps, 3), "n_ranks_rccl": world, "backend": dist.get_backend(),
-            "layers_per_rank": layers, "hops_per_verify": world - 1, "hop_bytes": hop_bytes,
-            "parallelism": f"pp{world}: target layers sharded, send/recv of the [T, H] activation per hop, one commit "
-                           "broadcast per iteration; draft + engine state on rank 0", "tree": "3x4", "scaling": "strong"}
+    r.update({"n_ranks_rccl": world, "backend": dist.get_backend(), "devices": census["devices"],
+              "n_distinct_devices": census["n_distinct"], "layers_per_rank": layers, "hops_per_verify": world - 1,
+              "hop_bytes": hop_bytes, "hop_us": hop_us, "acc": acc,
+              "parallelism": f"pp{world}: target layers sharded, send/recv of the [T, H] activation per hop, one commit "
+                             "broadcast per iteration; draft + engine state on rank 0", "tree": "3x4", "scaling": "strong"})
+    return r
 
 
 def run_pp_bench(args, wl, dtype, device, rank, world):
@@ -455,12 +483,13 @@ def run_pp_bench(args, wl, dtype, device, rank, world):
     r = pp_measure(args, wl, dtype, device, rank, world)
     out = None
     if r is not None:
-        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s_raw_draft"], "unit": "tokens/s",
+        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s"], "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
-               "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
+               "data": "synthetic: random-init weights, random prompt; acceptance set by the controllable-acceptance draft "
+                       "(the headline's acc vector and seed)",
                "config": {"workload": wl["desc"], "parallelism": r["parallelism"], "tree": "3x4", "prompt_len": args.prompt_len},
-               "accept_len": r["accept_len_raw_draft"], "pp": r}
+               "accept_len": r["accept_len"], "value_raw_draft": r["tokens_per_s_raw_draft"], "pp": r}
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -13,8 +13,9 @@ The layer chain is the SAME native one a single GPU runs (csrc/model.hip, the 8-
 wide dynamic trees, 1024-token prompt chunks): `umb_model_forward_tp` calls back for an all-reduce behind the two
 row-split GEMMs of every layer, and this module answers with RCCL (`torch.distributed` "nccl") on the launch stream --
 so a whole iteration, collectives included, still replays as ONE hipGraph per rank; at world 1 no collective is issued
-and the path is the plain engine's.  xGMI is point to point: a [T, H] fp32 tile (426 KB at T = 13, H = 8192; its 4
-split-K slabs travel together, 1.7 MB) is latency bound, 160 of them per 70B verify.
+and the path is the plain engine's.  xGMI is point to point: the collective carries exactly one [T, H] fp32 tile (T H 4
+bytes: 426 KB at T = 13, H = 8192 -- the split-K slabs are summed first, csrc/model.hip: tp_allreduce), latency bound,
+160 of them per 70B verify.
 The engines are the ordinary ones (static or dynamic, greedy or stochastic): the target they see is
 `TensorParallelLlama`, whose `logits_buffer` holds the all-gathered [T, V] logits, so sampling, accept scan and KV
 compaction are unchanged; every rank runs the same engine (SPMD) with the small draft replicated -- deterministic
@@ -193,6 +194,10 @@ class TensorParallelLlama:
         self._off = None
         self.sched = "split"
         self._err = None
+        # which transport answers the layer chain's all-reduce hook (reported on the bench line)
+        self.allreduce_path = ("gloo, host staged (tests: ranks sharing a GPU)" if comm.staged else
+                               f"{comm.backend}: torch.distributed all_reduce (RCCL) of one [T, H] fp32 tile on the launch "
+                               "stream, captured into the iteration hipGraph") if comm.live else "none"
 
         def hook(ctx, buf, count, stream):
             try:
@@ -344,45 +349,62 @@ def build_tp_engine(device: str, dtype=torch.float16, seed: int = 0, source=None
     return eng
 
 
+def allreduce_probe(device, numel, reps=50):
+    """One isolated all-reduce of the [T, H] fp32 tile a row-split GEMM hands over, on the launch stream, timed with
+    events behind a warm-up; -> microseconds per call (None in a 1-rank group or on a host-staged backend)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() < 2 or dist.get_backend() == "gloo":
+        return None
+    buf = torch.zeros(numel, dtype=torch.float32, device=device)
+    for _ in range(5):
+        dist.all_reduce(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0.record()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) * 1e3 / reps, 2)
+
+
 def tp_measure(args, wl, dtype, device, rank, world):
     """ONE request, every layer of the target split over the ranks of the default process group (static 3x4, greedy).
-    SPMD -- every rank runs this; all return the result dict.  Nothing is printed, the group stays up."""
-    import time
-
+    SPMD -- every rank runs this; all return the result dict.  Nothing is printed, the group stays up.
+    The acceptance knob is the headline's (same acc vector, same seed: speculation/steering.py; every rank steers with
+    the same recorded continuation, so the ranks keep taking identical decisions), `allreduce_us` = one isolated
+    all-reduce of the [T, H] fp32 tile, `devices` = the physical device identities gathered over the group."""
     import torch.distributed as dist
 
     import __graft_entry__ as ge
     from .models.config import KNOWN
-    from .sequoia_utils import generate_sequoia_tree
+    from .sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from .speculation.steering import device_census, steered_measure
     ge.build()
     cfg = KNOWN[wl["target"]]
+    census = device_census(device, dist if dist.is_initialized() else None)
+    gm = generate_sequoia_tree(3, 4)
+    ar_us = allreduce_probe(device, gm["size"] * cfg.hidden_size)
     eng = build_tp_engine(device, dtype=dtype, seed=args.seed, engine="static", model=wl["target"], draft_model=wl["draft"],
-                          growmap=generate_sequoia_tree(3, 4), max_length=args.max_length, exit_layer=16)
+                          growmap=gm, max_length=args.max_length, exit_layer=16)
     eng.initialize()
     g = torch.Generator().manual_seed(1234)
     prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, args.prompt_len), generator=g)
-    assert eng._prefill(prompt)
-    for _ in range(args.warmup):
-        eng.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    start = eng.num_nodes
-    t0 = time.time()
-    for _ in range(args.steps):
-        eng.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.time() - t0
-    tokens = eng.num_nodes - start
-    return {"ms_per_step": round(dt / args.steps * 1e3, 4), "tokens_per_s_raw_draft": round(tokens / dt, 2),
-            "accept_len_raw_draft": round(tokens / args.steps, 3), "n_ranks_rccl": world,
-            "backend": dist.get_backend() if dist.is_initialized() else "none",
-            "allreduces_per_verify": 2 * cfg.num_hidden_layers if world > 1 else 0,
-            "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4, "iteration_in_one_hipgraph": bool(eng.use_graph and eng.graph_scope == "iteration"),
-            "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 partial "
-                           "sums per layer inside the native layer chain; draft replicated", "tree": "3x4", "scaling": "strong"}
+    acc = list(DEFAULT_ACC)
+    barrier = dist.barrier if world > 1 else None
+    r = steered_measure(eng, prompt, acc, args.seed, args.warmup, args.steps, len(gm["roots"]), barrier=barrier)
+    tgt = eng.target_model
+    r.update({"n_ranks_rccl": dist.get_world_size() if dist.is_initialized() else 1,
+              "backend": dist.get_backend() if dist.is_initialized() else "none", "devices": census["devices"],
+              "n_distinct_devices": census["n_distinct"],
+              "allreduces_per_verify": 2 * cfg.num_hidden_layers if world > 1 else 0,
+              "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4, "allreduce_us": ar_us,
+              "allreduce_path": getattr(tgt, "allreduce_path", "none") if world > 1 else "none (1 rank: the hook is not called)",
+              "iteration_in_one_hipgraph": bool(eng.use_graph and eng.graph_scope == "iteration"), "acc": acc,
+              "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 partial "
+                             "sums per layer inside the native layer chain; draft replicated", "tree": "3x4", "scaling": "strong"})
+    return r
 
 
 def run_tp_bench(args, wl, dtype, device, rank, world):
@@ -393,12 +415,13 @@ def run_tp_bench(args, wl, dtype, device, rank, world):
     r = tp_measure(args, wl, dtype, device, rank, world)
     out = None
     if rank == 0:
-        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s_raw_draft"], "unit": "tokens/s",
+        out = {"metric": "tokens/s @ bs=1 (speculative decoding)", "value": r["tokens_per_s"], "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
-               "data": "synthetic: random-init weights, random prompt; raw draft (no acceptance knob)",
+               "data": "synthetic: random-init weights, random prompt; acceptance set by the controllable-acceptance draft "
+                       "(the headline's acc vector and seed)",
                "config": {"workload": wl["desc"], "parallelism": r["parallelism"], "tree": "3x4", "prompt_len": args.prompt_len},
-               "accept_len": r["accept_len_raw_draft"], "tp": r}
+               "accept_len": r["accept_len"], "value_raw_draft": r["tokens_per_s_raw_draft"], "tp": r}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():                                  # also the 1-rank group bench.py opens for the RCCL smoke run
         if world > 1:
