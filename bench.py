@@ -508,6 +508,8 @@ def headline(args, wl, dtype, device, rank, world, dist, agg_device):
 
     # ---- untimed: the target's own greedy continuation (ground truth for the acceptance knob)
     need = (args.warmup + args.steps) * len(gm["roots"]) + 16
+    from umbrella_amd.speculation.steering import disable_eos
+    disable_eos(eng)                  # random-init logits: an accepted EOS id would end the request inside the timed loop
     assert eng._prefill(prompt)
     start = eng.num_nodes
     torch.cuda.synchronize()
@@ -560,7 +562,7 @@ def headline(args, wl, dtype, device, rank, world, dist, agg_device):
     torch.cuda.synchronize()
     dt = time.time() - t0
     dt, tokens = aggregate(dt, tokens, world, dist, agg_device)
-    info = dict(start=start, raw_tps=raw_tps, raw_accept=raw_accept, passes=passes)
+    info = dict(start=start, raw_tps=raw_tps, raw_accept=raw_accept, passes=passes, head=[int(t) for t in truth[:8]])
     return eng, gm, acc, dt, tokens, info
 
 
@@ -604,7 +606,7 @@ def headline_line(args, wl, eng, gm, acc, dt, tokens, info, world):
                        if world > 1 else "single GPU"},
             "accept_len": round(accept_len, 3), "value_raw_draft": round(info["raw_tps"], 2),
             "accept_len_raw_draft": round(info["raw_accept"], 3), "oracle_draft_divergence": getattr(eng, "diverged", 0),
-            "oracle_draft_passes": info["passes"], "schedule": getattr(m, "sched", "split"),
+            "oracle_draft_passes": info["passes"], "continuation_head": info["head"], "schedule": getattr(m, "sched", "split"),
             "draft_forwards_per_iter": n_fwd, "iter_bytes_GB": round(bytes_iter / 1e9, 3),
             "iter_hbm_frac": round(bytes_iter / (iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -651,6 +653,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
+    if os.environ.get("UMB_BENCH_STACKS"):              # diagnostics: dump every thread's Python stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["UMB_BENCH_STACKS"]), repeat=False)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     self_launch(args)                                   # N > 1 outside torch.distributed.run: re-exec with N ranks

@@ -250,8 +250,11 @@ int umb_set_int(int* p, int v, umb_stream_t stream);
 /* target_logits[-1:, eos] = -inf (dynamic_speculation_engine.py:130,163) */
 int umb_mask_eos(float* logits_row, const int* eos, int n_eos, umb_stream_t stream);
 int umb_write_token(int* tokens_all, const int* n_ptr, const int* src, umb_stream_t stream);
-/* measurement knob: tokens_all[*n_ptr + off + i] = tbl[off + i] where tbl >= 0 (controllable-acceptance draft) */
-int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt, umb_stream_t stream);
+/* measurement knob: tokens_all[*n_ptr + off + i] = tbl[off + i] where tbl >= 0 (controllable-acceptance draft), i < cnt <= 1024.
+ * parents (tree tables, may be NULL): a sibling that already carries the forced token takes the displaced one, so the
+ * children of one parent stay distinct -- as the top-k that drafted them guarantees (static_speculation_engine.py:279-281). */
+int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, const int* parents, int off, int cnt,
+                       umb_stream_t stream);
 
 /* ------------------------------------------------------------------ whole-model forward */
 typedef struct UmbLinear {

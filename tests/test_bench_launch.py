@@ -72,3 +72,7 @@ def test_gpus2_shared_gpu_runs_replicas_pp_and_tp():
         assert out[leg]["n_distinct_devices"] == 1 and len(out[leg]["devices"]) == 1, out[leg]
         assert out[leg]["oracle_draft_divergence"] == 0
     assert "hop_us" in out["pp"] and "allreduce_us" in out["tp"] and out["status"] == "ok"
+    # the layer-sharded target IS the single-GPU model (same seeded weights, same kernels, same prompt as replica rank 0):
+    # its recorded continuation must be the replica's, token for token (round 4: an untied last stage drew another lm_head)
+    assert out["pp"]["continuation_head"] == out["continuation_head"], (out["pp"]["continuation_head"], out["continuation_head"])
+    assert out["pp"]["accept_len_raw_draft"] == out["accept_len_raw_draft"]

@@ -607,3 +607,27 @@ def test_full_width_70b_awq_layers_vs_fp32(dev):
     top2 = ref[P:].topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4 * float(err.max())
     assert torch.equal(got[P:].argmax(-1)[clear], ref[P:].argmax(-1)[clear])
+
+
+def test_override_keeps_siblings_distinct(dev):
+    """The acceptance knob (umb_apply_override) forces the target's token into one child slot; if a SIBLING already drafted
+    that token the two would both match the parent's sample and put two nodes of one depth on the accepted path (path
+    longer than depth + 1, a token committed twice).  The sibling takes the displaced token instead; other parents'
+    children and unforced levels are untouched."""
+    from umbrella_amd import _lib
+    n = 7
+    tokens = torch.zeros(64, dtype=torch.int32, device=dev)
+    # level of 6 nodes at tree offsets 4..9: parents 1,1,1 | 2,2,2
+    parents = torch.tensor([0, 0, 0, 0, 1, 1, 1, 2, 2, 2], dtype=torch.int32, device=dev)
+    tokens[n + 4:n + 10] = torch.tensor([50, 60, 70, 60, 80, 90], dtype=torch.int32, device=dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    tbl = torch.full((10,), -1, dtype=torch.int32, device=dev)
+    tbl[4] = 60                                   # forced into the first child of parent 1, whose second child drafted 60
+    _lib.call("umb_apply_override", tokens, n_dev, tbl, parents, 4, 6)
+    assert tokens[n + 4:n + 10].tolist() == [60, 50, 70, 60, 80, 90]      # sibling swapped; parent 2's own 60 untouched
+    tbl[4], tbl[9] = -1, 55                       # no sibling clash: a plain overwrite
+    _lib.call("umb_apply_override", tokens, n_dev, tbl, parents, 4, 6)
+    assert tokens[n + 4:n + 10].tolist() == [60, 50, 70, 60, 80, 55]
+    tbl[9] = 80
+    _lib.call("umb_apply_override", tokens, n_dev, tbl, None, 4, 6)       # parents == NULL: the round-3 behaviour
+    assert tokens[n + 4:n + 10].tolist() == [60, 50, 70, 60, 80, 80]

@@ -137,7 +137,7 @@ SIGNATURES = {
     "umb_set_int": [_P, _I, _P],
     "umb_mask_eos": [_P, _P, _I, _P],
     "umb_write_token": [_P, _P, _P, _P],
-    "umb_apply_override": [_P, _P, _P, _I, _I, _P],
+    "umb_apply_override": [_P, _P, _P, _P, _I, _I, _P],
     "umb_model_forward": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), _P],
     "umb_model_forward_tp": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), C.POINTER(UmbTP), _P],
     "umb_sum_splits": [_P, _I, C.c_int64, _P],

@@ -477,16 +477,29 @@ __global__ void mask_eos_last_row_kernel(float* logits_last_row, const int* eos,
 }
 __global__ void write_token_kernel(int* tokens_all, const int* n_ptr, const int* src) { tokens_all[*n_ptr] = src[0]; }
 
-// bench / test knob: force chosen tree slots to given tokens (tbl[i] < 0 keeps the drafted token)
-__global__ void apply_override_kernel(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt) {
-  const int i = threadIdx.x + blockIdx.x * blockDim.x;
-  if (i < cnt && tbl[off + i] >= 0) tokens_all[*n_ptr + off + i] = tbl[off + i];
+// bench / test knob: force chosen tree slots to given tokens (tbl[i] < 0 keeps the drafted token).  The drafted children of
+// one parent are distinct tokens (a top-k); a forced token that one of its SIBLINGS already carries would make two
+// children match the parent's sample and put two nodes of one depth on the accepted path, so that sibling takes the
+// displaced token instead (parents == NULL: no sibling check).  One block; a level holds at most 1024 nodes.
+__global__ void apply_override_kernel(int* tokens_all, const int* n_ptr, const int* tbl, const int* parents, int off, int cnt) {
+  const int n = *n_ptr;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int forced = tbl[off + i];
+    if (forced < 0) continue;
+    const int old = tokens_all[n + off + i];
+    if (parents && old != forced)
+      for (int j = 0; j < cnt; ++j)
+        if (j != i && parents[off + j] == parents[off + i] && tokens_all[n + off + j] == forced) tokens_all[n + off + j] = old;
+    tokens_all[n + off + i] = forced;
+  }
 }
 
 // ------------------------------------------------------------------ C entry points
-extern "C" int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, int off, int cnt, hipStream_t st) {
+extern "C" int umb_apply_override(int* tokens_all, const int* n_ptr, const int* tbl, const int* parents, int off, int cnt,
+                                  hipStream_t st) {
   if (cnt < 1) return UMB_OK;
-  hipLaunchKernelGGL(apply_override_kernel, dim3((cnt + 63) / 64), dim3(64), 0, st, tokens_all, n_ptr, tbl, off, cnt);
+  if (cnt > 1024) return UMB_EINVAL;
+  hipLaunchKernelGGL(apply_override_kernel, dim3(1), dim3(64), 0, st, tokens_all, n_ptr, tbl, parents, off, cnt);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

@@ -338,6 +338,12 @@ class Llama(LLMBase):
         self.embed_tokens = fetch("model.embed_tokens.weight", (Ve, H), "embed")[:Ve].to(dt).contiguous() \
             if (self.is_first or (self.is_last and c.tie_word_embeddings)) else None
         if self.is_last:
+            if reseed is not None:
+                # synthetic weights: the head has a stream of its own.  Drawn from the running stream it came AFTER the
+                # embedding on a single GPU but FIRST on the last stage of a layer-sharded target (which holds no
+                # embedding) -- an untied last stage then got the embedding's values as its head, i.e. another model
+                # than the one GPU runs (found with the tiny untied pair: the sharded run repeated its input token)
+                reseed.manual_seed(self._seed * 1000003 + 500009)
             head_w = self.embed_tokens if c.tie_word_embeddings else fetch("lm_head.weight", (V, H), "head")[:V].to(dt)
             assert head_w.shape == (V, H), (tuple(head_w.shape), V, H)
             self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)

@@ -151,7 +151,7 @@ class StaticSpeculationEngine(HipEngine):
                 if self.enable_override:
                     nxt = lv["off"] + lv["w"]
                     cnt = int(sum(self.branch_lists[self.levels.index(lv)]))
-                    _lib.call("umb_apply_override", self.tokens, self.n_dev, self.override_tbl, nxt, cnt)
+                    _lib.call("umb_apply_override", self.tokens, self.n_dev, self.override_tbl, self.parents, nxt, cnt)
 
     def _verify_forward(self):
         self.target_model.forward_tree(self.tokens, self.n_dev, self.depth, 0, self.tree_size, self.mask_bits,

@@ -23,10 +23,21 @@ def _run(eng, n):
     return eng.num_nodes - start
 
 
+def disable_eos(eng):
+    """Synthetic-weight measurements only: random-init logits make the EOS ids as likely as any other token, and an
+    accepted EOS ends a request (keep = its position: an EOS root keeps 0 tokens, so a fixed-length timing loop would
+    never advance).  The accept scan is launched with an empty EOS list instead -- its arguments are part of the captured
+    iteration, so call this before the first step()."""
+    eng.eos_tokens = []
+    eng.eos_dev = torch.tensor([-1], dtype=torch.int32, device=eng.device)
+    eng._graph = None
+
+
 def steered_measure(eng, prompt, acc, seed, warmup, steps, levels, barrier=None):
     """-> dict(ms_per_step, tokens, accept_len, raw_tokens_per_s, raw_accept_len, passes, divergence).
     `barrier`: optional callable bracketing the timed region (multi-rank SPMD engines)."""
     need = (warmup + steps) * levels + 16
+    disable_eos(eng)
     assert eng._prefill(prompt)
     start = eng.num_nodes
     torch.cuda.synchronize()
@@ -68,6 +79,7 @@ def steered_measure(eng, prompt, acc, seed, warmup, steps, levels, barrier=None)
     return {"ms_per_step": round(dt / steps * 1e3, 4), "tokens": tokens, "tokens_per_s": round(tokens / dt, 2),
             "accept_len": round(tokens / steps, 3), "tokens_per_s_raw_draft": round(raw_tokens / raw_dt, 2),
             "accept_len_raw_draft": round(raw_tokens / max(raw_steps, 1), 3), "oracle_draft_passes": passes,
+            "continuation_head": [int(t) for t in truth[:8]],
             "oracle_draft_divergence": getattr(eng, "diverged", div)}
 
 
