@@ -159,8 +159,12 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       xs[tt] = zero;
+#ifdef UMB_ABL_NOXS       // ablation (wrong results): no sum-of-x MFMA chain
+      xs[tt] = __builtin_bit_cast(f32x4, b[tt][0]);
+#else
 #pragma unroll
       for (int s = 0; s < 4; ++s) xs[tt] = P::mfma(ones, b[tt][s], xs[tt]);
+#endif
       xc[tt] = xs[tt] * (-COFF);                                      // C-in of the code chains: - C sum_k x_k
     }
 #pragma unroll
@@ -172,6 +176,10 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
       for (int s = 0; s < 4; ++s) {
         const unsigned w = st.a[r][0][s];
         u32x4 f;
+#ifdef UMB_ABL_NOUNPACK   // ablation (wrong results): raw dwords as the operand
+        f[0] = w; f[1] = w ^ magic; f[2] = w + magic; f[3] = w | magic;
+        if (false)
+#endif
         if constexpr (HALF) {
           f[0] = ((w << 4) & 0x00F000F0u) | magic;
           f[1] = (w & 0x00F000F0u) | magic;
@@ -195,6 +203,10 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
         const _Float16 zf = __builtin_bit_cast(_Float16, (u16)(st.m4[r][e] >> 16));
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
+#ifdef UMB_ABL_NOFIX      // ablation (wrong results): no fp32 scale / zero step
+          acc[r][tt][e] += ga[tt][e];
+          continue;
+#endif
           float t = __builtin_fmaf(-(float)zf, xs[tt][e], ga[tt][e]);
           asm("" : "+v"(t));
           acc[r][tt][e] = __builtin_fmaf((float)sc, t, acc[r][tt][e]);
