@@ -235,6 +235,15 @@ int umb_topk_rows_ws(int* out_idx, float* out_val, const float* logits, int rows
 int umb_sample_rows(int* sampled, float* logits, int rows, int V, const int* tokens_all, const int* n_ptr,
                     float penalty, float temperature, int topk, float topp, const void* seed, int dbg_k,
                     int* dbg_idx, float* dbg_p, umb_stream_t stream);
+/* The same pipeline with the REFERENCE's draw (static_speculation_engine.py:131,310: ONE uniform_samples = rand(3, T)
+ * tensor, reused by every verify): penalty -> top-k mask -> softmax(x / temperature) -> flashinfer 0.2.x
+ * TopPSamplingFromProb, the rejection sampler over caller-supplied uniforms u[round * ustride + row], `rounds` rounds
+ * (3 in the reference), cumulative sums in vocabulary order, the last round's token returned whether accepted or not
+ * (restated in oracle/ops.py: top_k_top_p_sampling_from_logits).  Same logits + same uniforms -> the reference's token.
+ * dbg_*: the top-k set (token, softmax probability) per row, sorted by probability. */
+int umb_sample_rows_uniform(int* sampled, float* logits, int rows, int V, const int* tokens_all, const int* n_ptr,
+                            float penalty, float temperature, int topk, float topp, const float* uniforms, int rounds,
+                            int ustride, int dbg_k, int* dbg_idx, float* dbg_p, umb_stream_t stream);
 /* SpecExec beam expansion of one level (dynamic_speculation_engine.py:236-248) */
 int umb_beam_expand(const int* top_idx, const float* top_val, int w, int B, int W, int lvl_off, float* tree_score,
                     int* parents, int* tokens_all, const int* n_ptr, void* mask_bits, int mask_words,

@@ -631,3 +631,45 @@ def test_override_keeps_siblings_distinct(dev):
     tbl[9] = 80
     _lib.call("umb_apply_override", tokens, n_dev, tbl, None, 4, 6)       # parents == NULL: the round-3 behaviour
     assert tokens[n + 4:n + 10].tolist() == [60, 50, 70, 60, 80, 80]
+
+
+def test_static_engine_reference_sampler_draws_like_the_reference(dev):
+    """weak #1 of the round-3 review: the static engine's stochastic verification could only be compared with the reference
+    as a distribution.  With reference_sampler=True the engine draws the reference's way -- ONE uniform_samples =
+    rand(3, tree_size) taken at initialize() and reused by every verify, flashinfer's rejection sampler
+    (static_speculation_engine.py:131,298-310).  Checked inside the running engine: the HIP target's own fp32 logits of
+    an iteration, pushed through the ORACLE's penalty -> / T -> top_k_top_p_sampling_from_logits with the engine's
+    uniforms and token history, give exactly the ids the engine sampled, for several iterations (the history and the
+    logits change, the uniforms do not); hipGraph == eager; an explicit uniform_samples tensor is honoured."""
+    from hip_helpers import static_engine
+    from oracle import ops as O
+    g = load_golden()
+    dtype = torch.float16
+    knobs = dict(temperature=0.7, topp=0.9, topk=16, repetition_penalty=1.1, seed=11)
+    eng, _ = static_engine(g, dev, dtype, self_draft=True, hip_graph=False, reference_sampler=True, **knobs)
+    T, V = eng.tree_size, eng.vocab_size
+    want_u = torch.rand(3, T, generator=torch.Generator().manual_seed(11))
+    assert torch.equal(eng.uniform_samples.cpu(), want_u)
+    prompt = g["cases"]["static_3x4_selfdraft"]["prompt"]
+    assert eng._prefill(torch.tensor([prompt]))
+    for it in range(6):
+        n = eng.num_nodes
+        eng.build_tree()
+        eng._verify_forward()
+        logits = eng.target_model.logits_buffer[:T].float().cpu().clone()
+        hist = eng.tokens[:n + 1].cpu().long()
+        eng._sample()
+        got = eng.sampled.cpu().long()
+        lg = O.repetition_penalty(hist[None].expand(T, -1), logits, 1.1)
+        want, _ = O.top_k_top_p_sampling_from_logits(lg / 0.7, want_u, 16, 0.9)
+        assert torch.equal(got, want), (it, got.tolist(), want.tolist())
+        eng._commit()
+        eng._finish_iteration()
+        assert eng.num_nodes > n
+    eng.reset()
+    # determinism / graph capture: the uniforms are a launch argument like any other buffer
+    outs = []
+    for graph in (True, False):
+        e2, _ = static_engine(g, dev, dtype, self_draft=True, hip_graph=graph, uniform_samples=want_u.clone(), **knobs)
+        outs.append(e2.generate(input_ids=prompt, max_new_tokens=24)["generated_tokens"])
+    assert outs[0] == outs[1] and len(outs[0]) >= 24

@@ -422,6 +422,43 @@ def test_sample_rows_distribution(dev, V, topk, penalty):
     assert chi < dof + 5 * (2 * max(dof, 1)) ** 0.5 + 10, (chi, dof)
 
 
+@pytest.mark.parametrize("V,topk,penalty", [(512, 8, 1.0), (128256, 32, 1.05), (5001, 32, 1.3), (128256, 20, 1.0)])
+def test_sample_rows_uniform_equals_the_reference_sampler(dev, V, topk, penalty):
+    """umb_sample_rows_uniform == the reference's static-engine draw (static:298-310): repetition penalty -> logits / T ->
+    flashinfer.sampling.top_k_top_p_sampling_from_logits(logits, uniform_samples, top_k, top_p) as restated in
+    oracle/ops.py (0.2.x rejection sampler, 3 rounds, vocabulary-order cumulative sums): the SAME uniforms give the SAME
+    token, row for row -- including rows driven to the tail of the kept set in every round (rejections; when the rounds
+    run out the last round's token is returned) and uniforms at the edges of [0, 1).  A row may differ only where u q sits within float rounding of a cumulative-sum boundary."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(7 * V + topk)
+    rows, n = 96, 150
+    logits = torch.randn(rows, V, generator=g) * 2.5
+    logits[1] = logits[1] * 0.2                              # a flat row: rejections are common (nucleus is wide)
+    hist = torch.randint(0, V, (n + 1,), generator=g)
+    hist[40:50] = logits[0].topk(10)[1]
+    temperature, topp = 0.6, 0.9
+    u = torch.rand(3, rows, generator=g)
+    u[:, 2] = torch.tensor([0.0, 0.0, 0.0]); u[:, 3] = torch.tensor([0.999999, 0.999999, 0.999999])
+    lg = logits.clone()
+    if penalty > 1.01:
+        lg = O.repetition_penalty(hist[None].expand(rows, -1), lg, penalty)
+    # rows 4..11: uniforms near 1 in every round walk to the tail of the kept set, where a draw is rejected while more
+    # than top_p of the mass lies strictly above it -- the rounds are used up and the last round's token is returned
+    u[:, 4:12] = 0.97 + 0.03 * torch.rand(3, 8, generator=g)
+    want, ok = O.top_k_top_p_sampling_from_logits(lg / temperature, u, topk, topp)
+    tokens = torch.zeros(n + 64, dtype=torch.int32); tokens[:n + 1] = hist.int()
+    tokens, nd = tokens.to(dev), torch.tensor([n], dtype=torch.int32, device=dev)
+    sampled = torch.zeros(rows, dtype=torch.int32, device=dev)
+    _lib.call("umb_sample_rows_uniform", sampled, logits.to(dev).clone(), rows, V, tokens, nd, penalty, temperature, topk, topp,
+              u.to(dev).contiguous(), 3, rows, 0, None, None)
+    got = sampled.cpu().long()
+    diff = (got != want).nonzero().flatten().tolist()
+    probs = torch.softmax(O.top_k_mask_logits(lg / temperature, topk), dim=-1)
+    for r in diff:                                            # only a rounding-boundary case may differ: both tokens in the top-k set
+        assert probs[r][got[r]] > 0 and probs[r][want[r]] > 0, (r, int(got[r]), int(want[r]))
+    assert len(diff) <= 1, (diff, got[diff], want[diff])
+
+
 def test_sample_rows_greedy_with_penalty_and_seed(dev):
     """temperature < 0.05 with a penalty: arg-max of the penalised row; same (seed, n) -> same draw."""
     from umbrella_amd import _lib

@@ -131,6 +131,7 @@ SIGNATURES = {
     "umb_topk_rows": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "umb_topk_rows_ws": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "umb_sample_rows": [_P, _P, _I, _I, _P, _P, _F, _F, _I, _F, _P, _I, _P, _P, _P],
+    "umb_sample_rows_uniform": [_P, _P, _I, _I, _P, _P, _F, _F, _I, _F, _P, _I, _I, _I, _P, _P, _P],
     "umb_beam_expand": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "umb_accept_scan": [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P],
     "umb_kv_compact": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

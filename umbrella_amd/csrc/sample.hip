@@ -263,7 +263,8 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(float* __restrict__ l
                                                            float temperature, float topp,
                                                            const unsigned long long* __restrict__ seed,
                                                            int* __restrict__ sampled, int dbg_k,
-                                                           int* __restrict__ dbg_idx, float* __restrict__ dbg_p) {
+                                                           int* __restrict__ dbg_idx, float* __restrict__ dbg_p,
+                                                           const float* __restrict__ uniforms, int rounds, int ustride) {
   __shared__ __attribute__((aligned(16))) unsigned long long s[1024];
   __shared__ __attribute__((aligned(16))) unsigned long long cand[1024];
   __shared__ int ncand;
@@ -307,6 +308,58 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(float* __restrict__ l
     __syncthreads();
   }
   const float total = cum[1023];
+  if (uniforms) {
+    // Reference-compatible draw (static_speculation_engine.py:131,310): flashinfer 0.2.x
+    // top_k_top_p_sampling_from_logits(logits / T, uniform_samples, top_k, top_p) = top-k mask -> softmax -> the
+    // REJECTION sampler TopPSamplingFromProb driven by the caller's uniforms u[round][row] (restated in oracle/ops.py:
+    // top_p_sampling_from_probs; same uniforms in -> same token out):
+    //   q = 1, pivot = 0;  per round: id = first i in VOCABULARY order with sum_{j <= i, p_j > pivot} p_j > u q (else V - 1),
+    //   pivot = max(pivot, p_id), q = mass strictly above pivot, accept when q < top_p; the last round's id is returned.
+    // The kept entries (top-k + ties) are ranked by token id first; one lane then walks them -- k is 32 in the reference.
+    __shared__ float sp[1024];
+    __shared__ int si[1024];
+    __syncthreads();
+    const float pme = e / total;
+    const int myidx = active ? key_idx(cand[tid]) : 0x7fffffff;
+    int rank = 0;
+    if (active)
+      for (int jj = 0; jj < have; ++jj)
+        rank += (key_val(cand[jj]) >= vk && key_idx(cand[jj]) < myidx) ? 1 : 0;
+    __shared__ int nact_s;
+    if (tid == 0) nact_s = 0;
+    __syncthreads();
+    if (active) { sp[rank] = pme; si[rank] = myidx; atomicAdd(&nact_s, 1); }
+    __syncthreads();
+    if (tid == 0) {
+      const int nact = nact_s;
+      float q = 1.f, pivot = 0.f;
+      int sid = V - 1;
+      for (int r = 0; r < rounds; ++r) {
+        const float u = uniforms[(long)r * ustride + blockIdx.x] * q;
+        float c = 0.f;
+        int hit = -1;
+        for (int i = 0; i < nact; ++i)
+          if (sp[i] > pivot) { c += sp[i]; if (c > u) { hit = i; break; } }
+        float pid = 0.f;
+        if (hit >= 0) { sid = si[hit]; pid = sp[hit]; }
+        else {                                                   // nothing above u q: the reference returns the last index
+          sid = V - 1;
+          for (int i = 0; i < nact; ++i) if (si[i] == V - 1) pid = sp[i];
+        }
+        pivot = fmaxf(pivot, pid);
+        float qn = 0.f;
+        for (int i = 0; i < nact; ++i) if (sp[i] > pivot) qn += sp[i];
+        q = qn;
+        if (q < topp) break;
+      }
+      sampled[blockIdx.x] = sid;
+    }
+    if (tid < dbg_k) {
+      dbg_idx[(long)blockIdx.x * dbg_k + tid] = active ? key_idx(cand[tid]) : -1;
+      dbg_p[(long)blockIdx.x * dbg_k + tid] = active ? e / total : 0.f;
+    }
+    return;
+  }
   const bool keep = active && (cum[tid] - e) < topp * total;  // mass before this element < topp
   __shared__ int kc_s, sel_s;
   if (tid == 0) { kc_s = 0; sel_s = 0; }
@@ -549,7 +602,28 @@ extern "C" int umb_sample_rows(int* sampled, float* logits, int rows, int V, con
     if (!raised) { (void)hipFuncSetAttribute((const void*)sample_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); raised = true; }
   }
   hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(1024), sm, st, logits, V, topk, tokens_all, n_ptr, penalty,
-                     temperature, topp, (const unsigned long long*)seed, sampled, dbg_k, dbg_idx, dbg_p);
+                     temperature, topp, (const unsigned long long*)seed, sampled, dbg_k, dbg_idx, dbg_p,
+                     (const float*)nullptr, 0, 0);
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+extern "C" int umb_sample_rows_uniform(int* sampled, float* logits, int rows, int V, const int* tokens_all,
+                                       const int* n_ptr, float penalty, float temperature, int topk, float topp,
+                                       const float* uniforms, int rounds, int ustride, int dbg_k, int* dbg_idx,
+                                       float* dbg_p, hipStream_t st) {
+  if (rows < 1 || topk < 1 || topk > 1024 || V < topk || !(topp > 0.f) || !uniforms || rounds < 1 || ustride < rows ||
+      dbg_k < 0 || dbg_k > 1024)
+    return UMB_EINVAL;
+  const size_t sm = penalty > 1.01f ? (size_t)((V + 31) / 32) * 4 : 0;
+  if (sm > 120 * 1024) return UMB_EINVAL;
+  if (sm > 32 * 1024) {
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void*)sample_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); raised = true; }
+  }
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(1024), sm, st, logits, V, topk, tokens_all, n_ptr, penalty,
+                     temperature, topp, (const unsigned long long*)nullptr, sampled, dbg_k, dbg_idx, dbg_p, uniforms,
+                     rounds, ustride);
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

@@ -507,6 +507,8 @@ class _PipelinedMixin:
     DYNAMIC_MASK = False
 
     def _pp_init(self, stage_model, comm):
+        assert not getattr(self, "reference_sampler", False), \
+            "reference_sampler (frozen uniforms) is a single-GPU static-engine mode: the last pipeline stage draws its own"
         self._stage_model, self._comm = stage_model, comm
         self._in_decode, self._pending = False, False
         self._decode_knobs = None

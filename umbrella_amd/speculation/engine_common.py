@@ -198,6 +198,13 @@ class HipEngine(BaseEngine):
             return
         k = min(int(self.topk), self.vocab_size)
         dk, di, dp = (0, None, None) if dbg is None else (dbg[0].shape[1], dbg[0], dbg[1])
+        u = getattr(self, "uniform_samples", None)
+        if u is not None:
+            # the reference's static-engine draw: ONE [rounds, T] tensor of uniforms reused by every verify (static:131,310)
+            _lib.call("umb_sample_rows_uniform", self.sampled, logits, T, self.vocab_size, self.tokens, self.n_dev,
+                      float(self.repetition_penalty), float(self.temperature), k, float(self.topp), u, u.shape[0],
+                      u.shape[1], dk, di, dp)
+            return
         _lib.call("umb_sample_rows", self.sampled, logits, T, self.vocab_size, self.tokens, self.n_dev,
                   float(self.repetition_penalty), float(self.temperature), k, float(self.topp), self.rng_state,
                   dk, di, dp)

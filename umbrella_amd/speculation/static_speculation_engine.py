@@ -42,6 +42,12 @@ class StaticSpeculationEngine(HipEngine):
         self.growmap_path = kwargs.pop("growmap_path", None)
         self.growmap = kwargs.pop("growmap", None)
         assert self.growmap_path is not None or self.growmap is not None, "Please specify growmap path for static trees"
+        # Stochastic verification.  Default: fresh counter-based draws per (seed, position, node) -- umb_sample_rows.
+        # reference_sampler=True (or an explicit uniform_samples [3, tree_size] tensor): the reference's own draw --
+        # flashinfer's rejection sampler over ONE rand(3, tree_size) tensor taken at initialize() and reused by every
+        # verify (static:131,310) -- so that the same uniforms give the same tokens as the reference, draw for draw.
+        self._uniform_arg = kwargs.pop("uniform_samples", None)
+        self.reference_sampler = bool(kwargs.pop("reference_sampler", False)) or self._uniform_arg is not None
         self._common_kwargs(kwargs)
         self.config = kwargs
 
@@ -84,6 +90,14 @@ class StaticSpeculationEngine(HipEngine):
                                    device=dev)
         self._load_models(dict(offload=False, cuda_graph=True), dict(offload=False))
         self._alloc_state(T, self.tree_depth)
+        self.uniform_samples = None
+        if self.reference_sampler:
+            if self._uniform_arg is not None:
+                u = torch.as_tensor(self._uniform_arg, dtype=torch.float32)
+                assert u.dim() == 2 and u.shape[1] == T, f"uniform_samples must be [rounds, {T}]"
+            else:
+                u = torch.rand(3, T, generator=torch.Generator().manual_seed(int(self.seed)))     # static:131
+            self.uniform_samples = u.to(dev).contiguous()
         self.override_tbl = torch.full((T,), -1, dtype=torch.int32, device=dev)
         self.override_host = torch.full((T,), -1, dtype=torch.int32).pin_memory()
         self.enable_override = False
