@@ -343,10 +343,40 @@ int umb_model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* 
  * descriptor): none, identical to umb_model_forward.  Needs ws->fused == 0 (the 8-launch schedule).  The logits of rows
  * [head_from, T) land in ws->logits as [rows][lm_head.N] = this rank's vocabulary slice. */
 typedef int (*umb_allreduce_fn)(void* ctx, float* buf, int64_t count, umb_stream_t stream);
+/* Direct-xGMI all-reduce of the small tiles (csrc/tp.hip; SURVEY 8(f)1 "fused all-reduce over xGMI", :248): every rank
+ * owns an exchange buffer [2][cap] floats + an epoch flag word, mapped into all peers (hipIpc*, umb_tp_xchg_*);
+ * umb_tp_publish sums this rank's split-K slabs into its slot and publishes the call's epoch at system scope,
+ * umb_tp_reduce_residual_norm waits for every peer's epoch and reads the P tiles through the peer pointers, summing in
+ * rank order (bit-identical on every rank), then residual + RMSNorm as umb_reduce_residual_norm.  No collective library,
+ * no ring: two launches in the rank's own stream where the single-GPU schedule has two (sum / reduce).
+ * slot[r], flag[r]: rank r's buffer / flag as mapped HERE (own entries: the local pointers).  epoch, arrive, status:
+ * local zero-initialised device words (calls so far; self-resetting block counter; 0 or 0xDEADxxxx after a peer failed
+ * to arrive within spin_limit polls, 0: ~2 s). */
+#define UMB_TP_MAX_RANKS 16
+typedef struct UmbTPPeer {
+  int32_t rank, world;
+  float* slot[UMB_TP_MAX_RANKS];
+  uint32_t* flag[UMB_TP_MAX_RANKS];
+  uint32_t* epoch; uint32_t* arrive; uint32_t* status;
+  int64_t cap;                      /* floats per slot */
+  int64_t spin_limit;
+} UmbTPPeer;
+int umb_tp_publish(const UmbTPPeer* peer, const float* partial, int S, int64_t n, umb_stream_t stream);
+int umb_tp_reduce_residual_norm(const UmbTPPeer* peer, int T, int N, const void* residual, void* h_out, void* xn_out,
+                                const void* w, float eps, int dtype, umb_stream_t stream);
+/* exchange memory: device allocation (fine-grained where the runtime allows; *fine_grained says which) + its 64-byte
+ * interprocess handle; open / close a peer's handle; free one's own.  Host-synchronous, load time only. */
+int umb_tp_xchg_alloc(size_t bytes, void** ptr, void* handle64, int* fine_grained);
+int umb_tp_xchg_open(const void* handle64, void** ptr);
+int umb_tp_xchg_close(void* ptr);
+int umb_tp_xchg_free(void* ptr);
 typedef struct UmbTP {
   int32_t rank, world;
-  umb_allreduce_fn allreduce;
+  umb_allreduce_fn allreduce;       /* the collective hook (RCCL on the launch stream; host-staged gloo in tests) */
   void* ctx;
+  const UmbTPPeer* peer;            /* NULL: every tile goes through the hook */
+  int64_t peer_max_floats;          /* tiles of at most this many floats take the peer path (one-shot reads move P - 1
+                                       tiles per rank, a ring 2 (P - 1) / P: large tiles stay on the hook) */
 } UmbTP;
 int umb_model_forward_tp(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* step, const UmbTP* tp,
                          umb_stream_t stream);

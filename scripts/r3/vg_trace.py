@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "umbrella_amd", "csrc")
 lib = os.path.join(ROOT, "gpurun_out", "libumbrella_vgtrace.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-srcs = ["gemm.hip", "lowlat.hip", "gemv.hip", "epilogue.hip", "attn.hip", "sample.hip", "model.hip"]
+srcs = ["gemm.hip", "lowlat.hip", "gemv.hip", "epilogue.hip", "attn.hip", "sample.hip", "tp.hip", "model.hip"]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUMB_VG_TRACE", *os.environ.get("VG_DEFS", "").split(),
                        "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-kernarg-preload-count=16",
                        *[os.path.join(CSRC, s) for s in srcs], "-o", lib], cwd=CSRC)

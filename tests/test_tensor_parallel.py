@@ -182,10 +182,11 @@ def test_tp_partials_sum_to_unsplit_linear(dev, awq):
 PROMPT = G["cases"]["static_3x4"]["prompt"]
 
 
-def _tp_gpu_worker(rank, world, port, q, awq):
-    """one tensor-parallel rank on cuda:0 (both ranks share the GPU): gloo carries the collectives through the host"""
+def _tp_gpu_worker(rank, world, port, q, awq, allreduce="auto"):
+    """one tensor-parallel rank on cuda:0 (both ranks share the GPU): gloo carries the collectives through the host;
+    allreduce = "peer": the small tiles go through the hipIpc-mapped exchange buffers instead (csrc/tp.hip)"""
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1", UMB_TP_ALLREDUCE=allreduce)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as ge
     ge.build()
@@ -223,6 +224,9 @@ def _tp_gpu_worker(rank, world, port, q, awq):
     d_prefill = float((row_tp - row).abs().max())
     d_tree = float((tp.logits_buffer[:T] - full.logits_buffer[:T]).abs().max())
     h_same = float((tp.m._bufs["h"][:T].float() - full._bufs["h"][:T].float()).abs().max())
+    h_bits = tp.m._bufs["h"][:T].view(torch.int16).to(torch.int64).cpu()
+    h_hash = int((h_bits * torch.arange(1, h_bits.numel() + 1).view_as(h_bits)).sum() % (2 ** 61 - 1))
+    path = tp.allreduce_path
     tp.clear()
     del full
     # ---- engines: the ordinary classes over the tensor-parallel target
@@ -240,22 +244,26 @@ def _tp_gpu_worker(rank, world, port, q, awq):
                                   repetition_penalty=1.05, seed=5)
     de.initialize()
     o3 = de.generate(input_ids=PROMPT, max_new_tokens=24)
-    q.put(dict(rank=rank, d_prefill=d_prefill, d_tree=d_tree, h=h_same, static=o1["generated_tokens"],
+    q.put(dict(rank=rank, d_prefill=d_prefill, d_tree=d_tree, h=h_same, h_hash=h_hash, path=path, static=o1["generated_tokens"],
                static_again=o2["generated_tokens"], accept=o1["avg_accept_tokens"], dynamic=o3["generated_tokens"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("allreduce", ["peer", "hook"])
 @pytest.mark.parametrize("awq", [False, True])
-def test_tp_two_ranks_share_one_gpu(dev, awq):
+def test_tp_two_ranks_share_one_gpu(dev, awq, allreduce):
+    """allreduce = "peer" (round 4): the [T, H] tiles of the tree verify and of the T <= 64 forwards are exchanged through
+    hipIpc-mapped buffers and summed in rank order inside the residual / norm kernel (no collective call); "hook": every
+    tile through the collective hook (host-staged gloo here, RCCL with one GPU per rank)."""
     import torch.multiprocessing as mp
     from hip_helpers import check_greedy
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, world, port, q, awq)) for r in range(world)]
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, world, port, q, awq, allreduce)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -267,6 +275,8 @@ def test_tp_two_ranks_share_one_gpu(dev, awq):
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
     a, b = got
+    assert a["path"].startswith("peer" if allreduce == "peer" else "gloo"), a["path"]
+    assert a["h_hash"] == b["h_hash"], "the ranks' residual streams differ in their bits: the sum is not in a fixed rank order"
     tol = 0.25 if awq else 0.12
     for g in got:                                   # sharded == unsharded up to fp32 summation order / 16-bit noise
         assert g["d_prefill"] < tol and g["d_tree"] < tol and g["h"] < 0.05, g
@@ -423,3 +433,70 @@ def test_tp8_shards_of_the_70b_awq_on_one_gpu(dev):
         assert torch.equal(tps[0].logits_buffer[:T], tps[7].logits_buffer[:T])
         assert torch.equal(tps[0].logits_buffer[:T].argmax(-1), ref.argmax(-1)) or \
             float((ref.max(-1).values - ref.gather(1, tps[0].logits_buffer[:T].argmax(-1, keepdim=True))[:, 0]).max()) < 2 * tol
+    # (the direct peer all-reduce is not run here: eight ranks as threads of ONE process share the process's four hardware
+    # queues, and a rank spinning for a peer whose kernels sit behind it in the same queue never sees it arrive -- the peer
+    # path needs ranks that run concurrently, i.e. one process per rank; it is covered at world 8 / H 8192 by
+    # test_tp_peer_kernels_equal_the_local_reduce and end to end by the two-process test above)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("world,T,N,S", [(2, 13, 8192, 4), (8, 13, 8192, 1), (4, 64, 2048, 8), (3, 5, 4100, 2)])
+def test_tp_peer_kernels_equal_the_local_reduce(dev, dtype, world, T, N, S):
+    """umb_tp_publish + umb_tp_reduce_residual_norm with all P "ranks" in one process (their exchange buffers are plain
+    device tensors here, no interprocess mapping): the result on EVERY rank equals umb_reduce_residual_norm over the P
+    summed tiles taken as P splits -- bit for bit, h and the normalised row --, over several calls (epoch parity: both
+    slots), with the publishes issued in a scrambled order (a rank may run ahead by one call, never by two)."""
+    import ctypes as C
+    from umbrella_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(world * 1000 + T)
+    cap = (T * N + 63) // 64 * 64
+    bufs = [torch.zeros(64 + 2 * cap, dtype=torch.float32, device=dev) for _ in range(world)]     # 256-byte flag line + 2 slots
+    words = [torch.zeros(64, dtype=torch.int32, device=dev) for _ in range(world)]
+    descs = []
+    for r in range(world):
+        d = _lib.UmbTPPeer()
+        d.rank, d.world, d.cap, d.spin_limit = r, world, cap, 1 << 20
+        for p in range(world):
+            d.flag[p] = bufs[p].data_ptr()
+            d.slot[p] = bufs[p].data_ptr() + 256
+        d.epoch, d.arrive, d.status = words[r].data_ptr(), words[r].data_ptr() + 64, words[r].data_ptr() + 128
+        descs.append(d)
+    w = (torch.randn(N, device=dev, generator=g) * 0.1 + 1.0).to(dtype)
+    dt = _lib.dtype_code(dtype)
+    for call in range(5):
+        parts = [torch.randn(S, T, N, device=dev, generator=g) * 0.5 for _ in range(world)]
+        resid = (torch.randn(T, N, device=dev, generator=g)).to(dtype)
+        # reference: the P tiles (each summed over its splits in split order) as P splits of the local kernel
+        tiles = torch.stack([p.clone() for p in parts])
+        for r in range(world):
+            _lib.call("umb_sum_splits", tiles[r], S, T * N)
+        stacked = tiles[:, 0].contiguous()                                        # [P][T][N]
+        h_ref, xn_ref = torch.empty(T, N, dtype=dtype, device=dev), torch.empty(T, N, dtype=dtype, device=dev)
+        if world <= 16 and N % 4 == 0:
+            _lib.call("umb_reduce_residual_norm", stacked, world, T, N, resid, h_ref, xn_ref, w, 1e-5, dt)
+        order = list(range(world))
+        if call % 2:
+            order.reverse()
+        for r in order:                                                            # every rank publishes ...
+            _lib.check(lib.umb_tp_publish(C.byref(descs[r]), C.c_void_p(parts[r].data_ptr()), S, T * N, _lib.stream_ptr()))
+        for r in order[::-1]:                                                      # ... then every rank reduces
+            h = resid.clone()
+            xn = torch.empty_like(h)
+            _lib.check(lib.umb_tp_reduce_residual_norm(C.byref(descs[r]), T, N, C.c_void_p(h.data_ptr()), C.c_void_p(h.data_ptr()),
+                                                       C.c_void_p(xn.data_ptr()), C.c_void_p(w.data_ptr()), 1e-5, dt,
+                                                       _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert int(words[r][32].item()) == 0, "a rank gave up waiting"
+            assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16)), (call, r)
+            assert torch.equal(xn.view(torch.int16), xn_ref.view(torch.int16)), (call, r)
+        assert all(int(wd[0].item()) == call + 1 for wd in words)
+    # a peer that never publishes: the bounded spin gives up and says so instead of hanging
+    lib.umb_tp_publish(C.byref(descs[0]), C.c_void_p(parts[0].data_ptr()), S, T * N, _lib.stream_ptr())
+    h = resid.clone()
+    descs[0].spin_limit = 2000
+    lib.umb_tp_reduce_residual_norm(C.byref(descs[0]), T, N, C.c_void_p(h.data_ptr()), C.c_void_p(h.data_ptr()), None,
+                                    None, 1e-5, dt, _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert (int(words[0][32].item()) & 0xffffffff) >> 16 == 0xDEAD

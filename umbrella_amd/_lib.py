@@ -82,8 +82,18 @@ class UmbStep(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
+TP_MAX_RANKS = 16
+
+
+class UmbTPPeer(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("slot", C.c_void_p * TP_MAX_RANKS),
+                ("flag", C.c_void_p * TP_MAX_RANKS), ("epoch", C.c_void_p), ("arrive", C.c_void_p), ("status", C.c_void_p),
+                ("cap", C.c_int64), ("spin_limit", C.c_int64)]
+
+
 class UmbTP(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p),
+                ("peer", C.POINTER(UmbTPPeer)), ("peer_max_floats", C.c_int64)]
 
 
 MAX_SLABS = 8
@@ -142,6 +152,12 @@ SIGNATURES = {
     "umb_model_forward": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), _P],
     "umb_model_forward_tp": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep), C.POINTER(UmbTP), _P],
     "umb_sum_splits": [_P, _I, C.c_int64, _P],
+    "umb_tp_publish": [C.POINTER(UmbTPPeer), _P, _I, C.c_int64, _P],
+    "umb_tp_reduce_residual_norm": [C.POINTER(UmbTPPeer), _I, _I, _P, _P, _P, _P, _F, _I, _P],
+    "umb_tp_xchg_alloc": [C.c_size_t, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_int)],
+    "umb_tp_xchg_open": [_P, C.POINTER(C.c_void_p)],
+    "umb_tp_xchg_close": [_P],
+    "umb_tp_xchg_free": [_P],
     "umb_model_forward_offload": [C.POINTER(UmbModel), C.POINTER(UmbWorkspace), C.POINTER(UmbStep),
                                   C.POINTER(UmbOffload), _P],
     "umb_bench_launch": [_I, _I, _P, _P],

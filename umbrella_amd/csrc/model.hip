@@ -66,9 +66,14 @@ static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
 // (umb_sum_splits, one ~5 us launch): the collective then carries exactly one [T, H] fp32 tile -- T H 4 bytes, 426 KB at
 // T = 13 -- instead of S of them (round 3 sent the four slabs of a T = 13 tile as they were: 1.7 MB per call, 160 calls per
 // 70B verify, on point-to-point links where such messages are latency- and per-link-bound).
-static inline bool tp_on(const UmbTP* tp) { return tp && tp->world > 1 && tp->allreduce; }
+static inline bool tp_on(const UmbTP* tp) { return tp && tp->world > 1 && (tp->allreduce || tp->peer); }
+// small tiles: direct peer reads (csrc/tp.hip); the choice depends on the tile size only -- the same on every rank
+static inline bool tp_peer(const UmbTP* tp, long TN) {
+  return tp && tp->world > 1 && tp->peer && TN <= tp->peer_max_floats && TN <= tp->peer->cap;
+}
 static int tp_allreduce(const UmbTP* tp, float* partial, int* S, long TN, hipStream_t st) {
   if (!tp_on(tp)) return UMB_OK;
+  if (!tp->allreduce) return UMB_EINVAL;                        // a tile too large for the peer path and no hook
   if (*S > 1) {
     CK(umb_sum_splits(partial, *S, TN, st));
     *S = 1;
@@ -93,15 +98,25 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
                    ws->attn_counters, dt, st));
   CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr, true));
   int So = eff_s(ly.o, T, true);
-  CK(tp_allreduce(tp, ws->partial, &So, (long)T * m->H, st));
-  CK(umb_reduce_residual_norm(ws->partial, So, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  if (tp_peer(tp, (long)T * m->H)) {
+    CK(umb_tp_publish(tp->peer, ws->partial, So, (int64_t)T * m->H, st));
+    CK(umb_tp_reduce_residual_norm(tp->peer, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  } else {
+    CK(tp_allreduce(tp, ws->partial, &So, (long)T * m->H, st));
+    CK(umb_reduce_residual_norm(ws->partial, So, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+  }
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
   CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
   CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr, true));
   int Sd = eff_s(ly.down, T, true);
-  CK(tp_allreduce(tp, ws->partial, &Sd, (long)T * m->H, st));
-  CK(umb_reduce_residual_norm(ws->partial, Sd, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt,
-                              st));
+  if (tp_peer(tp, (long)T * m->H)) {
+    CK(umb_tp_publish(tp->peer, ws->partial, Sd, (int64_t)T * m->H, st));
+    CK(umb_tp_reduce_residual_norm(tp->peer, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt, st));
+  } else {
+    CK(tp_allreduce(tp, ws->partial, &Sd, (long)T * m->H, st));
+    CK(umb_reduce_residual_norm(ws->partial, Sd, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt,
+                                st));
+  }
   return UMB_OK;
 }
 

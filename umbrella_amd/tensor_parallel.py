@@ -27,6 +27,7 @@ including its capture into the iteration graph.
 from __future__ import annotations
 
 import copy
+import os
 
 import torch
 
@@ -177,11 +178,68 @@ class TPComm:
         full.view(rows, self.world, Vl).copy_(buf.transpose(0, 1))
 
 
+# ------------------------------------------------------------------ direct peer all-reduce (csrc/tp.hip)
+class PeerExchange:
+    """The exchange buffers of the direct-xGMI all-reduce: every rank allocates [2][cap] floats + one flag line
+    (fine-grained device memory where the runtime allows), hands its interprocess handle round the group once, maps the
+    peers' buffers and fills an UmbTPPeer descriptor the native layer chain reads.  Setup only: the data path is two
+    kernel launches per all-reduce in the rank's own stream (umb_tp_publish / umb_tp_reduce_residual_norm)."""
+    FLAG_BYTES = 256
+
+    def __init__(self, comm: "TPComm", cap_floats: int, device):
+        import ctypes as C
+        dist = comm.dist
+        lib = _lib.load()
+        self.lib, self.world, self.rank = lib, comm.world, comm.rank
+        assert 2 <= self.world <= _lib.TP_MAX_RANKS
+        self.cap = (int(cap_floats) + 63) // 64 * 64
+        nbytes = 2 * self.cap * 4 + self.FLAG_BYTES
+        with torch.cuda.device(device):
+            base, fg = C.c_void_p(0), C.c_int(0)
+            handle = (C.c_ubyte * 64)()
+            _lib.check(lib.umb_tp_xchg_alloc(nbytes, C.byref(base), handle, C.byref(fg)), "umb_tp_xchg_alloc")
+            self.base, self.fine_grained = base.value, bool(fg.value)
+            handles = [None] * self.world
+            dist.all_gather_object(handles, (self.rank, bytes(handle), os.getpid()), group=comm.group)
+            self.peer_ptrs, self._opened = [0] * self.world, []
+            for r, hb, pid in handles:
+                if r == self.rank:
+                    self.peer_ptrs[r] = self.base
+                    continue
+                p = C.c_void_p(0)
+                buf = (C.c_ubyte * 64).from_buffer_copy(hb)
+                _lib.check(lib.umb_tp_xchg_open(buf, C.byref(p)), f"umb_tp_xchg_open(rank {r})")
+                self.peer_ptrs[r] = p.value
+                self._opened.append(p.value)
+        self.words = torch.zeros(64, dtype=torch.int32, device=device)       # epoch | arrive | status, 64 bytes apart
+        d = _lib.UmbTPPeer()
+        d.rank, d.world, d.cap, d.spin_limit = self.rank, self.world, self.cap, int(os.environ.get("UMB_TP_SPIN", "0"))
+        for r in range(self.world):
+            d.slot[r] = self.peer_ptrs[r] + self.FLAG_BYTES
+            d.flag[r] = self.peer_ptrs[r]
+        d.epoch, d.arrive, d.status = self.words.data_ptr(), self.words.data_ptr() + 64, self.words.data_ptr() + 128
+        self.desc = d
+        dist.barrier(group=comm.group)                # every mapping exists before anyone publishes
+
+    def status(self) -> int:
+        return int(self.words[32].item()) & 0xffffffff
+
+    def close(self):
+        for p in self._opened:
+            self.lib.umb_tp_xchg_close(p)
+        self._opened = []
+        if self.base:
+            self.lib.umb_tp_xchg_free(self.base)
+            self.base = 0
+
+
 # ------------------------------------------------------------------ the sharded target
 class TensorParallelLlama:
     """This rank's shard of one Llama target behind the model-runtime face the engines use.  `shard` is a `Llama` built on
     `local_config` (1/P of the heads, the MLP width and the vocabulary; whole embedding table) whose forward runs
     `umb_model_forward_tp`; this wrapper owns the all-reduce hook and the vocabulary all-gather of the logits."""
+
+    PEER_MAX_ROWS = 64                   # tiles of up to this many rows take the direct peer all-reduce (csrc/tp.hip)
 
     def __init__(self, cfg: LlamaCfg, shard, comm: TPComm, force_hook: bool = False):
         import ctypes as C
@@ -213,6 +271,25 @@ class TensorParallelLlama:
         # force_hook (tests): issue the collectives even in a 1-rank group (RCCL all-reduce over one rank = identity)
         tp.rank, tp.world = self.rank, (max(self.world, 2) if force_hook else self.world)
         tp.allreduce, tp.ctx = self._hook, None
+        # Direct peer reads for the small tiles (tree verify: T <= 64 rows): UMB_TP_ALLREDUCE = auto | peer | hook.  "auto"
+        # takes the peer path wherever the exchange buffers can be mapped (one GPU per rank over RCCL, or ranks sharing a
+        # GPU in the tests) and falls back to the hook with a warning; tiles above PEER_MAX_ROWS rows always take the hook.
+        self.peer = None
+        mode = os.environ.get("UMB_TP_ALLREDUCE", "auto")
+        if comm.live and comm.world > 1 and mode != "hook" and str(self.device).startswith("cuda"):
+            try:
+                self.peer = PeerExchange(comm, self.PEER_MAX_ROWS * cfg.hidden_size, self.device)
+                tp.peer = C.pointer(self.peer.desc)
+                tp.peer_max_floats = self.PEER_MAX_ROWS * cfg.hidden_size
+                self.allreduce_path = (f"peer: direct reads of the P [T, H] fp32 tiles through hipIpc-mapped exchange buffers "
+                                       f"({'fine-grained' if self.peer.fine_grained else 'ordinary'} device memory), summed in "
+                                       f"rank order inside the residual / norm kernel, for tiles of <= {self.PEER_MAX_ROWS} rows; "
+                                       "larger tiles: " + self.allreduce_path)
+            except Exception as e:
+                if mode == "peer":
+                    raise
+                import warnings
+                warnings.warn(f"tensor parallel: peer exchange unavailable ({type(e).__name__}: {e}); all-reduce through the hook")
         shard._tp = tp
         self._alloc_gather()
 
@@ -279,6 +356,13 @@ class TensorParallelLlama:
             raise
         self._raise_hook_error()
 
+    def _check_peer(self):
+        if self.peer is not None:
+            st = self.peer.status()
+            if st:
+                raise RuntimeError(f"tensor parallel: a peer never published its tile (status {st:#x}: row block {st & 0xffff}); "
+                                   "the group is out of step or a rank died")
+
     def _gather(self, rows):
         if rows > 0:
             self.comm.all_gather_columns(self.m._bufs["logits"][:rows], self._full[:rows], self._scratch)
@@ -311,12 +395,14 @@ class TensorParallelLlama:
             if last:
                 out = self._full[0]
         self.kv_cache.kv_offset = start + P
+        self._check_peer()                       # once per prompt and per clear(): never inside a captured iteration
         return out
 
     def gather_kv_incremental(self, indices, offset):
         self.kv_cache.gather_kv_incremental(indices, offset)
 
     def clear(self):
+        self._check_peer()
         self.m.clear()
 
     def weight_bytes(self):
