@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
 // at once): each span block publishes its merged partial with write-through stores and the last one to arrive on the
 // (head, tile) counter combines them (same protocol as the split-K epilogues).  grid = (Hkv, query tiles, spans):
 // kv head h stays on XCD h % 8.
-template <typename P, int D, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
+template <typename P, int D, int NW, int NQ = 1>
+__global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(const u16* __restrict__ q, const u16* __restrict__ kc,
                                                          const u16* __restrict__ vt, const int* __restrict__ prefix_p,
                                                          int T, int Hq, int Hkv, int Lmax, int mask_words, int n_mask_keys,
                                                          const unsigned long long* __restrict__ mask_bits,
@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
                                                          float* __restrict__ po, float* __restrict__ pml,
                                                          unsigned* __restrict__ counters, int out_fm_tt) {
   // argument order: the first 14 dwords (what the q / K loads need) are preloaded into SGPRs at wave launch
+  // NQ (round 4): query tiles per block.  Every K / V^T tile a wave loads serves NQ 16-row query tiles instead of one --
+  // the wide trees and prompt chunks (hundreds of query tiles per kv head) are bound by that L2 -> register traffic
+  // (T = 769: 385 query tiles x 8 kv heads each walking ~500 keys x 512 B = 0.8 GB per layer), not by the matrix pipe.
   constexpr int DS = D / 32, DT = D / 16;
   __shared__ f32x4 so[NW][DT][64];
   __shared__ float sm[NW][16], sl[NW][16];
@@ -223,30 +226,39 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
   const long LV = VT_LD(Lmax);
   const u16* vbase = vt + (long)h * D * LV;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const int row = qt * 16 + j;
-  const bool row_ok = row < nrows;
-  const int t = row_ok ? row / g : 0;
-  const int hq = h * g + (row_ok ? row % g : 0);
-  u32x4 bq[DS];
+  bool row_ok[NQ];
+  int t[NQ], hq[NQ];
+  u32x4 bq[NQ][DS];
+  float m[NQ], l[NQ];
+  f32x4 o[NQ][DT];
 #pragma unroll
-  for (int ds = 0; ds < DS; ++ds)
-    bq[ds] = row_ok ? *reinterpret_cast<const u32x4*>(q + ((long)t * Hq + hq) * D + ds * 32 + gq * 8) : zero4;
-  float m = NEG_BIG, l = 0.f;
-  f32x4 o[DT];
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int row = (qt * NQ + qi) * 16 + j;
+    row_ok[qi] = row < nrows;
+    t[qi] = row_ok[qi] ? row / g : 0;
+    hq[qi] = h * g + (row_ok[qi] ? row % g : 0);
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // Keys past the last one any row of this tile can see are never touched: in a tree (and in causal prefill) a node
+    for (int ds = 0; ds < DS; ++ds)
+      bq[qi][ds] = row_ok[qi] ? *reinterpret_cast<const u32x4*>(q + ((long)t[qi] * Hq + hq[qi]) * D + ds * 32 + gq * 8) : zero4;
+    m[qi] = NEG_BIG; l[qi] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // Keys past the last one any row of this block can see are never touched: in a tree (and in causal prefill) a node
   // sees no later node, so the tile of tokens [t0, t1] stops at prefix + t1 + 1 -- half of the tree keys on average.
   if (n_mask_keys > 64) {                                        // small trees: nothing worth skipping, no scan
-    int top = -1;                                                // highest visible tree key of this lane's row
-    if (row_ok && mask_bits) {
-      const unsigned long long* mrow = mask_bits + (long)t * mask_words;
-      for (int w = mask_words - 1; w >= 0; --w) {
-        const unsigned long long x = mrow[w];
-        if (x) { top = w * 64 + 63 - __clzll((long long)x); break; }
+    int top = -1;                                                // highest visible tree key of this lane's rows
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      if (row_ok[qi] && mask_bits) {
+        const unsigned long long* mrow = mask_bits + (long)t[qi] * mask_words;
+        for (int w = mask_words - 1; w >= 0; --w) {
+          const unsigned long long x = mrow[w];
+          if (x) { top = max(top, w * 64 + 63 - __clzll((long long)x)); break; }
+        }
+      } else if (row_ok[qi]) {
+        top = max(top, t[qi]);
       }
-    } else if (row_ok) {
-      top = t;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) top = max(top, __shfl_xor(top, off, 64));
@@ -271,59 +283,62 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
       av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * LV + k0 + gq * 8);
   };
   auto tile = [&](int k0, const u32x4 (&ak)[2][DS], const u32x4 (&av)[DT]) {
-    f32x4 st[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int qi = 0; qi < NQ; ++qi) {
+      f32x4 st[2];
 #pragma unroll
-      for (int ds = 0; ds < DS; ++ds) acc = P::mfma(ak[s][ds], bq[ds], acc);
-      st[s] = acc;
-    }
-    const int bfirst = k0 + gq * 8 - prefix;
-    unsigned vbits = 0xffu;                                     // bit e: key k0 + gq*8 + e visible to this row
-    if (k0 + 32 > prefix && bfirst > -8) {
-      const int neg = max(-bfirst, 0);                           // leading keys that still belong to the prefix
-      if (mask_bits) {
-        // the 8 mask bits starting at max(bfirst, 0), funnel-shifted out of two adjacent words
-        const int lo = max(bfirst, 0), wi = lo >> 6, sh = lo & 63;
-        const unsigned long long* mrow = mask_bits + (long)t * mask_words;
-        const unsigned long long w0 = mrow[min(wi, mask_words - 1)], w1 = mrow[min(wi + 1, mask_words - 1)];
-        unsigned long long x = w0 >> sh;
-        if (sh) x |= w1 << (64 - sh);
-        vbits = (unsigned)x & 0xffu;
-      } else {
-        const int n = min(max(t - max(bfirst, 0) + 1, 0), 8);      // causal: tree keys 0 .. t
-        vbits = (1u << n) - 1u;
+      for (int s = 0; s < 2; ++s) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) acc = P::mfma(ak[s][ds], bq[qi][ds], acc);
+        st[s] = acc;
       }
-      vbits = ((vbits << neg) | ((1u << neg) - 1u)) & 0xffu;
-    }
-    float pv[8];
-    float tmax = NEG_BIG;
+      const int bfirst = k0 + gq * 8 - prefix;
+      unsigned vbits = 0xffu;                                     // bit e: key k0 + gq*8 + e visible to this row
+      if (k0 + 32 > prefix && bfirst > -8) {
+        const int neg = max(-bfirst, 0);                           // leading keys that still belong to the prefix
+        if (mask_bits) {
+          // the 8 mask bits starting at max(bfirst, 0), funnel-shifted out of two adjacent words
+          const int lo = max(bfirst, 0), wi = lo >> 6, sh = lo & 63;
+          const unsigned long long* mrow = mask_bits + (long)t[qi] * mask_words;
+          const unsigned long long w0 = mrow[min(wi, mask_words - 1)], w1 = mrow[min(wi + 1, mask_words - 1)];
+          unsigned long long x = w0 >> sh;
+          if (sh) x |= w1 << (64 - sh);
+          vbits = (unsigned)x & 0xffu;
+        } else {
+          const int n = min(max(t[qi] - max(bfirst, 0) + 1, 0), 8);      // causal: tree keys 0 .. t
+          vbits = (1u << n) - 1u;
+        }
+        vbits = ((vbits << neg) | ((1u << neg) - 1u)) & 0xffu;
+      }
+      float pv[8];
+      float tmax = NEG_BIG;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int key = k0 + gq * 8 + e;
-      float sc = st[e >> 2][e & 3] * scale;
-      const bool vis = row_ok && key < k_hi && ((vbits >> e) & 1u);
-      sc = vis ? sc : -INFINITY;
-      pv[e] = sc;
-      tmax = fmaxf(tmax, sc);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);
-    const float alpha = __expf(m - m_new);
-    float psum = 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int key = k0 + gq * 8 + e;
+        float sc = st[e >> 2][e & 3] * scale;
+        const bool vis = row_ok[qi] && key < k_hi && ((vbits >> e) & 1u);
+        sc = vis ? sc : -INFINITY;
+        pv[e] = sc;
+        tmax = fmaxf(tmax, sc);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m[qi], tmax);
+      const float alpha = __expf(m[qi] - m_new);
+      float psum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pv[e] = __expf(pv[e] - m_new); psum += pv[e]; }
-    u32x4 pb;
+      for (int e = 0; e < 8; ++e) { pv[e] = __expf(pv[e] - m_new); psum += pv[e]; }
+      u32x4 pb;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) pb[e] = pack2<P>(pv[2 * e], pv[2 * e + 1]);
-    l = l * alpha + psum;
-    m = m_new;
+      for (int e = 0; e < 4; ++e) pb[e] = pack2<P>(pv[2 * e], pv[2 * e + 1]);
+      l[qi] = l[qi] * alpha + psum;
+      m[qi] = m_new;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      o[dt] *= alpha;
-      o[dt] = P::mfma(av[dt], pb, o[dt]);
+      for (int dt = 0; dt < DT; ++dt) {
+        o[qi][dt] *= alpha;
+        o[qi][dt] = P::mfma(av[dt], pb, o[qi][dt]);
+      }
     }
   };
 
@@ -338,101 +353,127 @@ __global__ __launch_bounds__(64 * NW, 2) void tree_attn1_kernel(const u16* __res
       tile(k1, kb2, vb);
     }
   }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  // ---- merge the NW wave partials through LDS; wave w finishes the d-tiles w, w + NW, ...
-  constexpr int NDT = (DT + NW - 1) / NW;
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) so[wv][dt][lane] = o[dt];
-  if (gq == 0) { sm[wv][j] = m; sl[wv][j] = l; }
-  __syncthreads();
   const int nsp = (kv_end + KBK - 1) / KBK;                     // span blocks that did not exit above
-  float M = NEG_BIG, L = 0.f;
-  f32x4 acc[NDT];
+  constexpr int NDT = (DT + NW - 1) / NW;
+  __shared__ int s_last;
+  bool last_known = false;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j]);
+  for (int qi = 0; qi < NQ; ++qi) {
+    float lq = l[qi];
+    lq += __shfl_xor(lq, 16, 64);
+    lq += __shfl_xor(lq, 32, 64);
+    // ---- merge the NW wave partials through LDS; wave w finishes the d-tiles w, w + NW, ...
+    if (qi > 0) __syncthreads();                                // the previous query tile's merge has read so / sm / sl
 #pragma unroll
-  for (int c = 0; c < NDT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) so[wv][dt][lane] = o[qi][dt];
+    if (gq == 0) { sm[wv][j] = m[qi]; sl[wv][j] = lq; }
+    __syncthreads();
+    float M = NEG_BIG, L = 0.f;
+    f32x4 acc[NDT];
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const float wt = __expf(sm[w][j] - M);
-    L += sl[w][j] * wt;
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][j]);
 #pragma unroll
-    for (int c = 0; c < NDT; ++c)
-      if (wv + c * NW < DT) acc[c] += so[w][wv + c * NW][lane] * wt;
-  }
-  const long orow = (long)t * Hq + hq;
-  auto store_out = [&](const f32x4& a, float inv, int dt) {
-    uint2 o2;
-    o2.x = pack2<P>(a[0] * inv, a[1] * inv); o2.y = pack2<P>(a[2] * inv, a[3] * inv);
-    if (out_fm_tt) {
-      // FM layout (MFMA B-fragment order of the o-projection, csrc/lowlat.hip): element (t, f = hq * D + d)
-      const int f = hq * D + dt * 16 + gq * 4;
-      const long off = ((((long)(f >> 5) * out_fm_tt + (t >> 4)) * 64 + ((f >> 3) & 3) * 16 + (t & 15)) << 3) + (f & 7);
-      *reinterpret_cast<uint2*>(out + off) = o2;
-    } else {
-      *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
-    }
-  };
-  if (nsp == 1) {
-    if (row_ok) {
-      const float inv = L > 0.f ? 1.f / L : 0.f;
+    for (int c = 0; c < NDT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wt = __expf(sm[w][j] - M);
+      L += sl[w][j] * wt;
 #pragma unroll
       for (int c = 0; c < NDT; ++c)
-        if (wv + c * NW < DT) store_out(acc[c], inv, wv + c * NW);
+        if (wv + c * NW < DT) acc[c] += so[w][wv + c * NW][lane] * wt;
     }
-    return;
+    const int tq = t[qi], hqq = hq[qi];
+    const bool rok = row_ok[qi];
+    const long orow = (long)tq * Hq + hqq;
+    auto store_out = [&](const f32x4& a, float inv, int dt) {
+      uint2 o2;
+      o2.x = pack2<P>(a[0] * inv, a[1] * inv); o2.y = pack2<P>(a[2] * inv, a[3] * inv);
+      if (out_fm_tt) {
+        // FM layout (MFMA B-fragment order of the o-projection, csrc/lowlat.hip): element (t, f = hq * D + d)
+        const int f = hqq * D + dt * 16 + gq * 4;
+        const long off = ((((long)(f >> 5) * out_fm_tt + (tq >> 4)) * 64 + ((f >> 3) & 3) * 16 + (tq & 15)) << 3) + (f & 7);
+        *reinterpret_cast<uint2*>(out + off) = o2;
+      } else {
+        *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
+      }
+    };
+    if (nsp == 1) {
+      if (rok) {
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+#pragma unroll
+        for (int c = 0; c < NDT; ++c)
+          if (wv + c * NW < DT) store_out(acc[c], inv, wv + c * NW);
+      }
+      continue;
+    }
+    // ---- more than one span: publish (M, L, acc) write-through, last arriver combines
+    const long rows_all = (long)T * Hq;
+    if (rok) {
+      const long prow = (long)blockIdx.z * rows_all + orow;
+      const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < NDT; ++c)
+        if (wv + c * NW < DT)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[c]), rs_o,
+                                                 (int)((prow * D + (wv + c * NW) * 16 + gq * 4) * 4), 0, 16);
+      if (wv == 0 && gq == 0) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
+        u32x2 ml = {__float_as_uint(M), __float_as_uint(L)};
+        __builtin_amdgcn_raw_buffer_store_b64(ml, rs_m, (int)(prow * 8), 0, 16);
+      }
+    }
+    if (qi + 1 < NQ) continue;                                   // one ticket per block, after its last query tile is out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned* cnt = counters + (long)h * gridDim.y + qt;
+      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == (unsigned)(nsp - 1);
+      if (last) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    last_known = true;
   }
-  // ---- more than one span: publish (M, L, acc) write-through, last arriver combines
+  if (!last_known || !s_last) return;
+  // the last span block of this (head, query-tile group) combines every span's partials, query tile by query tile
   const long rows_all = (long)T * Hq;
-  if (row_ok) {
-    const long prow = (long)blockIdx.z * rows_all + orow;
-    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc(po, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < NDT; ++c)
-      if (wv + c * NW < DT)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[c]), rs_o,
-                                               (int)((prow * D + (wv + c * NW) * 16 + gq * 4) * 4), 0, 16);
-    if (wv == 0 && gq == 0) {
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(pml, 0, 0x7fffffff, 0x00020000);
-      u32x2 ml = {__float_as_uint(M), __float_as_uint(L)};
-      __builtin_amdgcn_raw_buffer_store_b64(ml, rs_m, (int)(prow * 8), 0, 16);
-    }
-  }
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* cnt = counters + (long)h * gridDim.y + qt;
-    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = ticket == (unsigned)(nsp - 1);
-    if (last) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last || !row_ok) return;
-  float Mg = NEG_BIG;
-  for (int s2 = 0; s2 < nsp; ++s2) Mg = fmaxf(Mg, pml[(s2 * rows_all + orow) * 2]);
-  float Lg = 0.f;
-  for (int s2 = 0; s2 < nsp; ++s2) {
-    const long pr = s2 * rows_all + orow;
-    Lg += pml[pr * 2 + 1] * __expf(pml[pr * 2] - Mg);
-  }
-  const float inv = Lg > 0.f ? 1.f / Lg : 0.f;
-#pragma unroll
-  for (int c = 0; c < NDT; ++c) {
-    const int dt = wv + c * NW;
-    if (dt >= DT) continue;
-    f32x4 ag = {0.f, 0.f, 0.f, 0.f};
+  for (int qi = 0; qi < NQ; ++qi) {
+    if (!row_ok[qi]) continue;
+    const int tq = t[qi], hqq = hq[qi];
+    const long orow = (long)tq * Hq + hqq;
+    float Mg = NEG_BIG;
+    for (int s2 = 0; s2 < nsp; ++s2) Mg = fmaxf(Mg, pml[(s2 * rows_all + orow) * 2]);
+    float Lg = 0.f;
     for (int s2 = 0; s2 < nsp; ++s2) {
       const long pr = s2 * rows_all + orow;
-      ag += *reinterpret_cast<const f32x4*>(po + pr * D + dt * 16 + gq * 4) * __expf(pml[pr * 2] - Mg);
+      Lg += pml[pr * 2 + 1] * __expf(pml[pr * 2] - Mg);
     }
-    store_out(ag, inv, dt);
+    const float inv = Lg > 0.f ? 1.f / Lg : 0.f;
+#pragma unroll
+    for (int c = 0; c < NDT; ++c) {
+      const int dt = wv + c * NW;
+      if (dt >= DT) continue;
+      f32x4 ag = {0.f, 0.f, 0.f, 0.f};
+      for (int s2 = 0; s2 < nsp; ++s2) {
+        const long pr = s2 * rows_all + orow;
+        ag += *reinterpret_cast<const f32x4*>(po + pr * D + dt * 16 + gq * 4) * __expf(pml[pr * 2] - Mg);
+      }
+      uint2 o2;
+      o2.x = pack2<P>(ag[0] * inv, ag[1] * inv); o2.y = pack2<P>(ag[2] * inv, ag[3] * inv);
+      if (out_fm_tt) {
+        const int f = hqq * D + dt * 16 + gq * 4;
+        const long off = ((((long)(f >> 5) * out_fm_tt + (tq >> 4)) * 64 + ((f >> 3) & 3) * 16 + (tq & 15)) << 3) + (f & 7);
+        *reinterpret_cast<uint2*>(out + off) = o2;
+      } else {
+        *reinterpret_cast<uint2*>(out + orow * D + dt * 16 + gq * 4) = o2;
+      }
+    }
   }
 }
 
@@ -496,14 +537,19 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
     static const int nw_env = getenv("UMB_ATTN_NW") ? atoi(getenv("UMB_ATTN_NW")) : 0;
     const int nblk = Hkv * nqt;
     const int nw = nw_env ? nw_env : nblk >= 2048 ? 1 : nblk >= 512 ? 2 : 8;
-    const dim3 grid1(Hkv, nqt, spans), block1(64 * nw);
-#define ATT1N_(DD, NWV)                                                                                           \
-  hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache,    \
+    // query tiles per block: two once the launch has a thousand (kv head, query tile) pairs (wide trees, prompt chunks):
+    // each K / V^T tile a wave pulls from L2 then feeds two query tiles (UMB_ATTN_NQ=1: the round-3 kernel, A/B)
+    static const int nq_env = getenv("UMB_ATTN_NQ") ? atoi(getenv("UMB_ATTN_NQ")) : 0;
+    const int nq = (nw > 2 || nblk < 1536) ? 1 : nq_env ? (nq_env >= 2 ? 2 : 1) : 2;   // T = 257 (1032 pairs): 24.3 vs 25.4 us, stays at one
+    const dim3 grid1(Hkv, (nqt + nq - 1) / nq, spans), block1(64 * nw);
+#define ATT1N_(DD, NWV, NQV)                                                                                      \
+  hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV, NQV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache, \
                      (const u16*)vt_cache, prefix_len, T, Hq, Hkv, Lmax, mask_words, n_mask_keys,                   \
                      (const unsigned long long*)mask_bits, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt)
 #define ATT1_(DD)                                                                                                 \
-  if (nw == 1) { ATT1N_(DD, 1); } else if (nw == 2) { ATT1N_(DD, 2); } else if (nw == 4) { ATT1N_(DD, 4); }       \
-  else { ATT1N_(DD, 8); }
+  if (nw == 1 && nq == 2) { ATT1N_(DD, 1, 2); } else if (nw == 1) { ATT1N_(DD, 1, 1); }                            \
+  else if (nw == 2 && nq == 2) { ATT1N_(DD, 2, 2); } else if (nw == 2) { ATT1N_(DD, 2, 1); }                       \
+  else if (nw == 4) { ATT1N_(DD, 4, 1); } else { ATT1N_(DD, 8, 1); }
     DISPATCH_DTYPE(dtype, {
       if (D == 128) { ATT1_(128) }
       else if (D == 64) { ATT1_(64) }
