@@ -467,7 +467,13 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
   // Slab order restarts at 0.  (The slabs still in use by the last NS layers of THIS forward are reused in ring order,
   // each copy gated by its own ev_free.)
   if (pf && nfirst > 0) {
-    for (int i = 0; i < nfirst; ++i) CK(issue_copy(first[i], i));
+    // When every streamed layer of the range fits the ring at once (n_streamed <= NS) no in-loop copy overwrote a slab:
+    // slab i still holds first[i], and the next forward finds its layers in place -- nothing crosses the link again
+    // (the epilogue used to re-issue all of them every forward, ~444 MB per slab for the 70B-AWQ).
+    int n_streamed = 0;
+    for (int l = lb; l < le; ++l) n_streamed += off->host_slabs[l] != nullptr;
+    if (n_streamed > NS)
+      for (int i = 0; i < nfirst; ++i) CK(issue_copy(first[i], i));
     for (int i = 0; i < NS; ++i) pf[i] = first[i];
   }
   if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
