@@ -1088,6 +1088,9 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   const int kb0 = ks0 >> 1, kb1 = ks1 >> 1;
   // single loads, so that the M phase can issue them one at a time between its MFMA groups
   auto load_w1 = [&](int kb_, int q) {                               // int4 tile q of block kb_ (dense: its four k32 tiles)
+#ifdef UMB_PP_NOWLOAD      // ablation (wrong results): the weights of the first block only
+    if (kb_ > kb0) return;
+#endif
     const int kb = min(kb_, kb1 - 1);                                // past the slab: a harmless reload of its last block
     if (AWQ) {
       ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (kb * 4 + q) * 1024, 0);
@@ -1098,10 +1101,16 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
     }
   };
   auto load_m1 = [&](int kb_, int q) {
+#ifdef UMB_PP_NOWLOAD
+    if (kb_ > kb0) return;
+#endif
     const int kb = min(kb_, kb1 - 1);
     if (AWQ) rm[q] = __builtin_amdgcn_raw_buffer_load_b32(rmt, j * 4, (kb * 4 + q) * 64, 0);
   };
   auto load_x1 = [&](int ks_, int i) {
+#ifdef UMB_PP_NOXLOAD      // ablation (wrong results): the activations of the first step only
+    if (ks_ > ks0) return;
+#endif
     const int ks = min(ks_, ks1 - 1);
     rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voffx[i], ks * 128, 0);
   };
@@ -1114,6 +1123,9 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
     for (int i = 0; i < FPW; ++i) load_x1(ks_, i);
   };
   auto sstore = [&]() {
+#ifdef UMB_PP_NOSTORE      // ablation (wrong results): no activation stores to LDS
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < FPW; ++i)
       if (NF % 4 == 0 || i * 4 + wv < NF) sB[(i * 4 + wv) * 64 + lane] = rb[i];
@@ -1198,8 +1210,12 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
     for (int i = 0; i < NF; ++i) {
       const int t = i >> 1, sx = i & 1;
       if (i + BD < NF) bq[(i + BD) % (BD + 1)] = sb[(i + BD) * 64];
+#ifdef UMB_PP_NOMFMA       // ablation (wrong results): the phase without its matrix instructions
+      asm volatile("" :: "v"(bq[i % (BD + 1)]), "v"(wf[0][sx]), "v"(wf[1][sx]), "v"(wf[2][sx]), "v"(wf[3][sx]));
+#else
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q][t] = P::mfma(wf[q][sx], bq[i % (BD + 1)], acc[q][t]);
+#endif
 #ifdef UMB_PP_NOFENCE
 #define PP_FENCE() do {} while (0)
 #else
