@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void verify_gemm_r_kernel(const u32x4* __re
 #ifndef UMB_PP_LM
 #define UMB_PP_LM 7
 #endif
-template <typename P, int AWQ, int TT>
+template <typename P, int AWQ, int TT, int SHX = 0>
 __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __restrict__ wp,
                                                              const unsigned char* __restrict__ meta,
                                                              const u16* __restrict__ x, int ldx, int T, int Tv, int N, int K,
@@ -1038,15 +1038,21 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NF = TT * 2;                                         // activation fragments per 64-k step
   constexpr int FPW = (NF + 3) / 4;                                  // staged per wave
+  // SHX (round 4): the two work items of the workgroup are neighbouring ROW blocks of the SAME token chunk and stage its
+  // activations ONCE -- two buffers by step parity, each group loading and storing half of a step's fragments (group 1 one step
+  // ahead of its own compute, so that both halves are in place when group 0 reads them).  The activations' trip registers -> LDS
+  // is 8 % of this kernel's wall time (profiles/r04_vgemm_pp32_negative.txt, 6): half the ds_write_b128 per MFMA.
+  constexpr int FH = SHX ? (FPW + 1) / 2 : FPW;                      // fragments this wave loads / stores per step
   const int lane = threadIdx.x & 63;
   const int wv8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wv8 >> 2, wv = wv8 & 3;
-  u32x4* sB = reinterpret_cast<u32x4*>(smem) + grp * NF * 64;        // one buffer per group: [TT][2 s][64]
+  u32x4* sB = reinterpret_cast<u32x4*>(smem) + (SHX ? 0 : grp * NF * 64);   // one buffer per group: [TT][2 s][64] (SHX: per step parity)
+  const int ibase = SHX ? grp * (FPW / 2) : 0;                       // SHX: group 0 stages fragment rows i = 0 .. FPW/2 - 1, group 1 the rest
   const int j = lane & 15, g = lane >> 4;
   const int nblk = N / 256;
   const int nchunk = (Tv + TT * 16 - 1) / (TT * 16);
   int nb, tc, sp;
-  if (pair_tc) {                                                     // groups: token chunks 2 q, 2 q + 1 of the same rows
+  if (!SHX && pair_tc) {                                             // groups: token chunks 2 q, 2 q + 1 of the same rows
     const int hc = nchunk / 2;
     nb = blockIdx.x % nblk; tc = 2 * ((blockIdx.x / nblk) % hc) + grp; sp = blockIdx.x / (nblk * hc);
   } else {                                                           // groups: row blocks 2 q, 2 q + 1
@@ -1071,11 +1077,13 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   const auto rmt = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(AWQ ? meta + tile_base * 64 : (const unsigned char*)wp), 0,
                                                      AWQ ? (unsigned)KB * 256u : 0u, 0x00020000);
   const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(x), 0, (unsigned)(((long)(Tv - 1) * ldx + K) * 2), 0x00020000);
-  int voffx[FPW];
+  int voffx[FH], soff[FH];
 #pragma unroll
-  for (int i = 0; i < FPW; ++i) {
-    const int f = i * 4 + wv, tok = t0 + (f >> 1) * 16 + j;
-    voffx[i] = (f < NF && tok < Tv) ? (int)(((long)tok * ldx + (f & 1) * 32 + g * 8) * 2) : (int)0x80000000;
+  for (int i = 0; i < FH; ++i) {
+    const int f = (ibase + i) * 4 + wv, tok = t0 + (f >> 1) * 16 + j;
+    const bool mine = f < NF && (!SHX || grp == 1 || i < FPW / 2);   // SHX, odd FPW: the extra row is group 1's
+    voffx[i] = (mine && tok < Tv) ? (int)(((long)tok * ldx + (f & 1) * 32 + g * 8) * 2) : (int)0x80000000;
+    soff[i] = (mine ? f * 64 : 2 * NF * 64) + lane;                  // a fragment that is not this wave's goes to a dump slot
   }
   // Loads are the X phase's long pole (phase trace, scripts/r3/vg_trace.py: 13 buffer loads per step cost ~940 cycles of
   // issue with four waves of the CU in their X phase at once -- the texture-address path takes a wave64 load every ~16
@@ -1084,7 +1092,7 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   u32x4 ra[4];                                                       // int4: the lane's four dwords (4 x k32) of this 128-k block, per n-tile
   unsigned rm[4];
   u32x4 rd[AWQ ? 1 : 4][AWQ ? 1 : 4];                                // dense: the four 16 x 32 tiles of this block, per n-tile
-  u32x4 rb[FPW];
+  u32x4 rb[FH];
   const int kb0 = ks0 >> 1, kb1 = ks1 >> 1;
   // single loads, so that the M phase can issue them one at a time between its MFMA groups
   auto load_w1 = [&](int kb_, int q) {                               // int4 tile q of block kb_ (dense: its four k32 tiles)
@@ -1120,15 +1128,21 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   };
   auto gload_x = [&](int ks_) {
 #pragma unroll
-    for (int i = 0; i < FPW; ++i) load_x1(ks_, i);
+    for (int i = 0; i < FH; ++i) load_x1(ks_, i);
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int par_store) {
 #ifdef UMB_PP_NOSTORE      // ablation (wrong results): no activation stores to LDS
     return;
 #endif
+    if constexpr (SHX) {
+      // group 0 stores this step's half into the buffer of this step's parity, group 1 the NEXT step's half into the other one
 #pragma unroll
-    for (int i = 0; i < FPW; ++i)
-      if (NF % 4 == 0 || i * 4 + wv < NF) sB[(i * 4 + wv) * 64 + lane] = rb[i];
+      for (int i = 0; i < FH; ++i) sB[par_store * NF * 64 + soff[i]] = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < FPW; ++i)
+        if (NF % 4 == 0 || i * 4 + wv < NF) sB[(i * 4 + wv) * 64 + lane] = rb[i];
+    }
   };
 #ifdef UMB_VG_TRACE
   unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -1139,7 +1153,7 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
   auto step = [&](auto hc, int kb) {
     constexpr int HF = decltype(hc)::value;                          // which 64-k half of the block
     // ---- X phase: this step's activations to LDS, its weights dequantised, the next loads issued
-    sstore();
+    sstore(SHX ? (HF ^ grp) : 0);
 #ifdef UMB_VG_TRACE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -1180,7 +1194,7 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
 #endif
     VG_T(1);
     // which loads the M phase issues (bit 0 activations, 1 weights, 2 metadata); the rest go out here
-    if (!(UMB_PP_LM & 1)) gload_x(2 * kb + HF + 1);
+    if (!(UMB_PP_LM & 1)) gload_x(2 * kb + HF + 1 + (SHX ? grp : 0));
     if (HF == 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1198,7 +1212,7 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
 #else
     constexpr int BD = 3;
 #endif
-    const u32x4* sb = sB + lane;
+    const u32x4* sb = sB + (SHX ? HF * NF * 64 : 0) + lane;
     u32x4 bq[BD + 1];
 #pragma unroll
     for (int i = 0; i < BD; ++i) bq[i] = sb[i * 64];
@@ -1224,7 +1238,7 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
       // The next loads go out HERE, one per MFMA group: issued from the X phase they cost ~90 cycles each (four waves of the
       // CU queue on the texture-address path at once); between MFMAs the issue slots are free.  Registers: rb was
       // stored at the start of this step's X phase, ra / rm were consumed by its dequant.
-      if ((UMB_PP_LM & 1) && (i & 1) == 1 && (i >> 1) < FPW) load_x1(2 * kb + HF + 1, i >> 1);
+      if ((UMB_PP_LM & 1) && (i & 1) == 1 && (i >> 1) < FH) load_x1(2 * kb + HF + 1 + (SHX ? grp : 0), i >> 1);
       if ((UMB_PP_LM & 2) && HF == 1 && i >= NF - 8 && i < NF - 4) load_w1(kb + 1, i - (NF - 8));
       if ((UMB_PP_LM & 4) && HF == 1 && i >= NF - 4) load_m1(kb + 1, i - (NF - 4));
       PP_FENCE();
@@ -1242,7 +1256,14 @@ __global__ __launch_bounds__(512) void verify_gemm_pp_kernel(const u32x4* __rest
     gload_x(ks0);
     gload_w(kb0);
   }
-  if (grp == 1) __syncthreads();                                     // stagger: group 1 runs one phase behind group 0
+  if (grp == 1) {
+    if constexpr (SHX) {
+      // group 1's half of the FIRST step goes out before the stagger barrier (group 0 reads it in its first M phase);
+      // from then on group 1 carries the activations of the step after the one it computes
+      if (kb0 < kb1) { sstore(0); gload_x(ks0 + 1); }
+    }
+    __syncthreads();                                                 // stagger: group 1 runs one phase behind group 0
+  }
   for (int kb = kb0; kb < kb1; ++kb) {
     step(std::integral_constant<int, 0>{}, kb);
     step(std::integral_constant<int, 1>{}, kb);
@@ -1299,6 +1320,20 @@ static int launch_verify(const void* wp, const void* meta, const u16* x, int ldx
       const int pair_tc = nch % 2 == 0;
       if constexpr (AWQ == 2) if (!no_pp && (pair_tc || (N / 256) % 2 == 0)) {      // int4 only (a dense 128-k block of tiles is 64 registers)
         const unsigned grid = (unsigned)((N / 256) * nch * S / 2);
+        // shared activation staging: the two work items are neighbouring row blocks of one token chunk (UMB_PP_SHX=0: the
+        // round-3 pairing -- same rows, neighbouring token chunks, each group staging its own activations)
+        static const bool shx = getenv("UMB_PP_SHX") == nullptr || atoi(getenv("UMB_PP_SHX")) != 0;
+        if (shx && (N / 256) % 2 == 0) {
+          if (tt9) {
+            hipLaunchKernelGGL((verify_gemm_pp_kernel<P, AWQ, 9, 1>), dim3(grid), dim3(512), (size_t)(2 * 18 + 1) * 64 * 16, st,
+                               (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, Tv, N, K, S, epi, 0, out, fx);
+          } else {
+            hipLaunchKernelGGL((verify_gemm_pp_kernel<P, AWQ, 8, 1>), dim3(grid), dim3(512), (size_t)(2 * 16 + 1) * 64 * 16, st,
+                               (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, Tv, N, K, S, epi, 0, out, fx);
+          }
+          UMB_LAUNCH_CHECK();
+          return UMB_OK;
+        }
         if (tt9) {
           hipLaunchKernelGGL((verify_gemm_pp_kernel<P, AWQ, 9>), dim3(grid), dim3(512), (size_t)2 * 18 * 64 * 16, st,
                              (const u32x4*)wp, (const unsigned char*)meta, x, ldx, T, Tv, N, K, S, epi, pair_tc, out, fx);
