@@ -205,6 +205,21 @@ def _tp_gpu_worker(rank, world, port, q, awq, allreduce="auto"):
     assert comm.world == world and comm.staged
     tp = TensorParallelLlama.build(cfg, sd, comm, 256, str(dev), dtype)
     assert tp.m.config.num_attention_heads == cfg.num_attention_heads // world and tp.m.lm_head.N == cfg.vocab_size // world
+    if allreduce == "peer":
+        # the load-time self check (peer path vs the collective hook on one forward) passes here ...
+        assert tp.peer is not None and tp.peer_self_check() and tp.allreduce_path.startswith("peer")
+        # ... and catches a transport that does not deliver: with the peers' slot pointers bent to this rank's own buffer
+        # every rank sums its own tile P times -- the check must fail on both ranks and fall back to the hook
+        good = [tp.peer.desc.slot[r] for r in range(world)]
+        for r in range(world):
+            tp.peer.desc.slot[r] = good[rank]
+        ok_bent = tp.peer_self_check()
+        assert not ok_bent and tp.allreduce_path.startswith("hook only"), (ok_bent, tp.last_self_check, tp.allreduce_path)
+        for r in range(world):
+            tp.peer.desc.slot[r] = good[r]
+        tp.m._tp.peer = tp._peer_ptr
+        tp.peer_disabled = False
+        tp.allreduce_path = "peer (restored after the sabotage test)"
     # ---- model level: prefix + a 13-node tree vs the unsharded HIP model
     full, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, awq=awq)
     gm = growmap("3x4")

@@ -279,7 +279,8 @@ class TensorParallelLlama:
         if comm.live and comm.world > 1 and mode != "hook" and str(self.device).startswith("cuda"):
             try:
                 self.peer = PeerExchange(comm, self.PEER_MAX_ROWS * cfg.hidden_size, self.device)
-                tp.peer = C.pointer(self.peer.desc)
+                self._peer_ptr = C.pointer(self.peer.desc)       # kept: reading `tp.peer` back yields a VIEW of the field, not a copy
+                tp.peer = self._peer_ptr
                 tp.peer_max_floats = self.PEER_MAX_ROWS * cfg.hidden_size
                 self.allreduce_path = (f"peer: direct reads of the P [T, H] fp32 tiles through hipIpc-mapped exchange buffers "
                                        f"({'fine-grained' if self.peer.fine_grained else 'ordinary'} device memory), summed in "
@@ -356,8 +357,48 @@ class TensorParallelLlama:
             raise
         self._raise_hook_error()
 
+    def peer_self_check(self, rows: int = 13, tol: float = 0.05) -> bool:
+        """The direct peer all-reduce has only ever run with the ranks on ONE device (where every rank shares an L2); on a
+        real node its cross-device visibility is decided by the hardware.  So before it is trusted: one T-row forward through
+        the peer path and the same forward through the collective hook (RCCL) -- both deterministic, both summing the P tiles --
+        must give the same logits up to fp32 summation order on EVERY rank; otherwise the peer path is switched off for this
+        model (collectively) and `allreduce_path` says so.  Costs two small forwards at load time."""
+        if self.peer is None or self.world < 2:
+            return True
+        import ctypes as C
+        dev = self.device
+        g = torch.Generator().manual_seed(97)
+        ids = torch.randint(3, max(4, self.config.vocab_size - 1), (rows,), generator=g).int().to(dev)
+        pos = torch.arange(rows, dtype=torch.int32, device=dev)
+        pre = torch.zeros(1, dtype=torch.int32, device=dev)
+        tp = self.m._tp
+        saved = self._peer_ptr
+        outs = []
+        for use_peer in (True, False):
+            tp.peer = saved if use_peer else C.POINTER(_lib.UmbTPPeer)()
+            self.m.clear()
+            self.forward_explicit(ids, pos, pos, pre, head_from=0)
+            torch.cuda.synchronize()
+            outs.append(self.logits_buffer[:rows].clone())
+        self.m.clear()
+        scale = float(outs[1].abs().max())
+        diff = float((outs[0] - outs[1]).abs().max())
+        self.last_self_check = {"max_abs_diff": diff, "scale": scale}
+        bad = not (diff <= tol * max(scale, 1.0)) or self.peer.status() != 0
+        flag = torch.tensor([1.0 if bad else 0.0], device="cpu" if self.comm.staged else dev)
+        self.comm.dist.all_reduce(flag, group=self.comm.group)          # any rank's doubt switches every rank off
+        ok = float(flag[0]) == 0.0
+        if ok:
+            tp.peer = saved
+        else:
+            tp.peer = C.POINTER(_lib.UmbTPPeer)()
+            self.allreduce_path = "hook only (the peer all-reduce FAILED its self-check against the collective on this node): " + \
+                self.allreduce_path.split("larger tiles: ")[-1]
+            self.peer_disabled = True
+        return ok
+
     def _check_peer(self):
-        if self.peer is not None:
+        if self.peer is not None and not getattr(self, "peer_disabled", False):
             st = self.peer.status()
             if st:
                 raise RuntimeError(f"tensor parallel: a peer never published its tile (status {st:#x}: row block {st & 0xffff}); "
@@ -425,6 +466,7 @@ def build_tp_engine(device: str, dtype=torch.float16, seed: int = 0, source=None
     if source is None:
         source = LazySyntheticShard(cfg, comm.rank, comm.world, device, dtype, seed=seed)
     tp = TensorParallelLlama.build(cfg, source, comm, max_length, device, dtype, name=target, seed=seed, force_hook=force_hook)
+    tp.peer_self_check()
     for k in ("offload", "num_cache_layers"):                    # single-GPU placement knobs of the reference
         config.pop(k, None)
     if config.get("engine", "dynamic") == "dynamic":
@@ -487,6 +529,7 @@ def tp_measure(args, wl, dtype, device, rank, world):
               "allreduces_per_verify": 2 * cfg.num_hidden_layers if world > 1 else 0,
               "allreduce_bytes": eng.tree_size * cfg.hidden_size * 4, "allreduce_us": ar_us,
               "allreduce_path": getattr(tgt, "allreduce_path", "none") if world > 1 else "none (1 rank: the hook is not called)",
+              "peer_self_check": getattr(tgt, "last_self_check", None),
               "iteration_in_one_hipgraph": bool(eng.use_graph and eng.graph_scope == "iteration"), "acc": acc,
               "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 partial "
                              "sums per layer inside the native layer chain; draft replicated", "tree": "3x4", "scaling": "strong"})
