@@ -423,6 +423,19 @@ def secondary_configs(device, seed=0):
             shared["t"] = t
         return shared["t"]
 
+    def pmc_mfma_busy(T):
+        """MFMA-busy of the wide verify GEMM from the COMMITTED counter pass of this build's kernel (PMC cannot be read from
+        inside the timed process: `scripts/collect_r04.sh` -> profiles/, summarised by scripts/pmc_mfma_busy.py).  Not live:
+        the file name travels with the figure."""
+        name = f"r04_pmc_verify_gemm_T{769 if T > 512 else 256}_mfma_busy.json"
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                ks = [k for k in json.load(f)["kernels"] if "verify_gemm_pp_kernel" in k["kernel"] and "mfma_busy" in k]
+            return {"source": f"profiles/{name} (committed rocprofv3 --pmc pass, not measured by this run)",
+                    "by_blocks": {str(k["blocks"]): k["mfma_busy"] for k in ks}}
+        except Exception:
+            return None
+
     def verify_rate(eng):
         """dense MFMA rate of the verify forward alone (events on the launch stream), 2 T (layer + head parameters) flops"""
         t = eng.target_model
@@ -430,7 +443,7 @@ def secondary_configs(device, seed=0):
         params = sum(ln.N * ln.K for ln in t.layers[0].values()) * t.num_layers + t.lm_head.N * t.lm_head.K
         tf = 2.0 * eng.tree_size * params / (ms * 1e-3) / 1e12
         return {"verify_ms": round(ms, 2), "verify_TFLOPs": round(tf, 1), "bound": "mfma",
-                "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
+                "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "mfma_busy": pmc_mfma_busy(eng.tree_size)}
 
     def c3_resident():
         t = target70()
