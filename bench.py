@@ -290,8 +290,11 @@ def _oracle_state(cfg, layers, alias):
     layer's RAM)."""
     from umbrella_amd.models.synthetic import linear_shapes
 
-    def rnd(n, k):      # timing only: a materialised rank-1 random matrix costs one pass over memory instead of a Gaussian draw per element
-        return (torch.randn(n, 1) * 0.14) * (torch.randn(1, k) * 0.14)
+    pool = torch.randn((1 << 24) + 12347) * 0.02        # Gaussian entries; the period shares no factor with any row length
+
+    def rnd(n, k):      # every element a Gaussian draw from the pool laid end to end (no two rows equal, no rank-1 structure);
+        reps = -(-(n * k) // pool.numel())               # costs one pass over memory instead of 4 G serial mt19937 draws
+        return pool.repeat(reps)[:n * k].view(n, k)
     sd = {"model.embed_tokens.weight": rnd(cfg.vocab_size, cfg.hidden_size),
           "model.norm.weight": torch.ones(cfg.hidden_size)}
     if not cfg.tie_word_embeddings:
@@ -351,8 +354,8 @@ def cpu_baseline(wl, gm, accept_len, threads):
             "iteration_s": round(it, 3), "draft_s": round(t_draft, 3), "verify_s": round(t_target, 3),
             "sample": f"1 whole static iteration measured end to end with the oracle (torch CPU fp32): {len(widths)} draft "
                       f"forwards (rows {widths}) on the full draft + the {T}-row verify through all {layers} target layers "
-                      f"and the lm_head, context 128; target layers alias one layer's fp32 tensors (RAM), same arithmetic "
-                      f"and traffic; tokens/s at the GPU run's accept_len {accept_len:.2f}"}
+                      f"and the lm_head, context 128; Gaussian weights; target layers alias one layer's fp32 tensors (RAM), same "
+                      f"arithmetic and traffic; tokens/s at the GPU run's accept_len {accept_len:.2f}"}
 
 
 # ------------------------------------------------------------------ secondary configurations (BASELINE configs 2-4), N = 1
