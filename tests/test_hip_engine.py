@@ -172,6 +172,38 @@ def test_dynamic_wide_tree_and_offload(dev):
         assert out["generated_tokens"] == ref["generated_tokens"]
 
 
+@pytest.mark.parametrize("width,num_beams,depth,awq", [(16, 24, 16, False), (16, 24, 24, True), (21, 24, 24, True)])
+def test_dynamic_reference_config_tree_shapes(dev, width, num_beams, depth, awq):
+    """The dynamic tree shapes the reference's own config files ask for (configs/{chat,greedy}_config_{12,16,24}gb.json:
+    width 16 / 21, num_beams 24 > width, depth 16 / 24 -> 257 / 385 / 505 tokens per verify; the 16gb / 24gb pair drafts with
+    an AWQ model, 21 rows per level is a ragged second token tile) on the tiny model: greedy tokens are arg-maxes of the fp32
+    oracle, the hipGraph iteration equals the eager one, and the stochastic iteration replays under its seed."""
+    from hip_helpers import check_greedy, dynamic_engine
+    dtype = torch.float16
+    L = 1024
+    eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=width, num_beams=num_beams, depth=depth, max_length=L,
+                             awq=awq)
+    assert eng.tree_size == width * depth + 1
+    ref = eng.generate(input_ids=PROMPT, max_new_tokens=48)
+    toks = ref["generated_tokens"]
+    assert len(toks) >= 40
+    # an AWQ target is checked against the oracle on the dequantised weights at the AWQ tests' tolerance
+    check_greedy(G, sd, PROMPT, toks, dtype, mask_first_eos=eng.eos_tokens, tol=0.12 if awq else None)
+    assert ref["avg_accept_tokens"] > 2.5, ref["avg_accept_tokens"]          # self-draft: deep paths are accepted
+    del eng
+    eager, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=width, num_beams=num_beams, depth=depth, max_length=L,
+                              awq=awq, hip_graph=False)
+    assert eager.generate(input_ids=PROMPT, max_new_tokens=48)["generated_tokens"] == toks
+    del eager
+    outs = []
+    for graph in (True, False):
+        st, _ = dynamic_engine(G, dev, dtype, self_draft=True, width=width, num_beams=num_beams, depth=depth, max_length=L,
+                               awq=awq, hip_graph=graph, temperature=0.6, topp=0.9, topk=32, seed=11)
+        outs.append(st.generate(input_ids=PROMPT, max_new_tokens=32)["generated_tokens"])
+        del st
+    assert outs[0] == outs[1] and len(outs[0]) >= 24
+
+
 def test_stochastic_sampling_support(dev):
     """temperature > 0: sampled tokens stay inside the top-k / top-p support of the oracle's filtered
     target distribution (distributional parity only -- RNG streams differ)."""
