@@ -1526,7 +1526,9 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
     // k-blocks per LDS chunk (= half the weight ring) by token tiles.  Fewer = fewer registers = more waves per SIMD;
     // measured optima below (UMB_CB / UMB_CB2 / UMB_CB4 override: experiments)
     static const int cb1 = getenv("UMB_CB") ? atoi(getenv("UMB_CB")) : UMB_CB1;
-    static const int cb2 = getenv("UMB_CB2") ? atoi(getenv("UMB_CB2")) : 1;      // 16 layers of the 70B at T = 31: 3.50 (CB 4) / 2.79 / 2.78 ms
+    // 16 layers of the 70B at T = 31: 3.50 (CB 4) / 2.79 / 2.78 ms.  Round 4: int4 takes 2 -- the 8B-AWQ draft at 32 rows (one 4-wave
+    // block per CU on gate/up and o: the ring depth IS the bytes in flight) 2.63 -> 2.54 ms per forward, 21 rows 2.49 -> 2.43; 4: 2.86
+    static const int cb2 = getenv("UMB_CB2") ? atoi(getenv("UMB_CB2")) : (AWQ ? 2 : 1);
     static const int cb4 = getenv("UMB_CB4") ? atoi(getenv("UMB_CB4")) : 1;      // T = 64: 4.96 (CB 2) / 4.60 ms
 #define UMB_LR(TTV, CBV) rc = launch_r<P, AWQ, TTV, CBV>(R, wp, meta, xx, ldx, oo, tn, T, N, K, S, epi, fx, st, tb)
     if (tn <= 16) { if (cb1 == 1) UMB_LR(1, 1); else if (cb1 == 2) UMB_LR(1, 2); else UMB_LR(1, 4); }
