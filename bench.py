@@ -358,6 +358,35 @@ def cpu_baseline(wl, gm, accept_len, threads):
                       f"arithmetic and traffic; tokens/s at the GPU run's accept_len {accept_len:.2f}"}
 
 
+# ------------------------------------------------------------------ the headline configuration at other prompt lengths
+def context_sweep(eng, wl, gm, acc, args):
+    """synthetic prompts of P in {64, 128, 256, 512} tokens (MT-Bench turn 1 with its system prompt is 70-420).
+    The headline is P = 128; here the same engine, tree, acceptance knob and procedure at the other lengths plus one prompt
+    that nearly fills max_length -- what the context costs the iteration (tree attention and the KV reads; the weights'
+    44 GB do not change).  Bounded step counts; a failure here never takes the headline with it."""
+    from umbrella_amd.speculation.steering import steered_measure
+    out = {}
+    lengths = [64, 256, 512, max(512, args.max_length - 512)]
+    if os.environ.get("UMB_BENCH_CONTEXTS"):                       # experiments: "512,900"
+        lengths = [int(v) for v in os.environ["UMB_BENCH_CONTEXTS"].split(",")]
+    steps = int(os.environ.get("UMB_BENCH_CONTEXT_STEPS", 16))
+    for P in lengths:
+        try:
+            g = torch.Generator().manual_seed(4321 + P)
+            prompt = torch.randint(3, wl.get("vocab_hi", 128000), (1, P), generator=g)
+            eng.reset()
+            r = steered_measure(eng, prompt, acc, args.seed, 4, steps, len(gm["roots"]))
+            out[str(P)] = {"ms_per_step": r["ms_per_step"], "accept_len": r["accept_len"],
+                           "tokens_per_s": r["tokens_per_s"]}
+        except Exception as e:
+            out[str(P)] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        eng.reset()
+    except Exception:
+        pass
+    return out
+
+
 # ------------------------------------------------------------------ secondary configurations (BASELINE configs 2-4), N = 1
 def _timed_steps(eng, prompt, warm, steps):
     assert eng._prefill(prompt)
@@ -735,6 +764,8 @@ def main():
     if world == 1:
         if not args.no_roofline:
             out["roofline"] = roofline_block(eng)
+        if not args.no_secondary and args.workload == "70b-awq+1b":
+            out["context_sweep"] = context_sweep(eng, wl, gm, acc, args)
         del eng
         torch.cuda.empty_cache()
         if not args.no_secondary and args.workload == "70b-awq+1b":

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
                                                          const unsigned long long* __restrict__ mask_bits,
                                                          float scale, u16* __restrict__ out, int KBK,
                                                          float* __restrict__ po, float* __restrict__ pml,
-                                                         unsigned* __restrict__ counters, int out_fm_tt) {
+                                                         unsigned* __restrict__ counters, int out_fm_tt, int single_max) {
   // argument order: the first 14 dwords (what the q / K loads need) are preloaded into SGPRs at wave launch
   // NQ (round 4): query tiles per block.  Every K / V^T tile a wave loads serves NQ 16-row query tiles instead of one --
   // the wide trees and prompt chunks (hundreds of query tiles per kv head) are bound by that L2 -> register traffic
@@ -220,8 +220,11 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
   }
   const int prefix = *prefix_p;
   const int kv_end = prefix + n_mask_keys;
-  if (k_lo >= kv_end) return;                                  // whole block: span not in use yet
-  int k_hi = min(kv_end, k_lo + KBK);
+  // A context of <= single_max keys is ONE span whatever KBK is (span 0 walks all of it, the other spans' blocks leave):
+  // the cross-block merge costs a narrow launch ~2 us, which 512-key spans only win back once there are several of them
+  const bool one_span = kv_end <= single_max;
+  if (one_span ? blockIdx.z > 0 : k_lo >= kv_end) return;      // whole block: span not in use (yet)
+  int k_hi = one_span ? kv_end : min(kv_end, k_lo + KBK);
   const u16* kbase = kc + (long)h * Lmax * D;
   const long LV = VT_LD(Lmax);
   const u16* vbase = vt + (long)h * D * LV;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
       tile(k1, kb2, vb);
     }
   }
-  const int nsp = (kv_end + KBK - 1) / KBK;                     // span blocks that did not exit above
+  const int nsp = one_span ? 1 : (kv_end + KBK - 1) / KBK;     // span blocks that did not exit above
   constexpr int NDT = (DT + NW - 1) / NW;
   __shared__ int s_last;
   bool last_known = false;
@@ -528,7 +531,21 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
   // context outgrows a span); without one only when a single span covers Lmax.  The choice depends on Lmax alone
   // (kv_end lives on the device), so a captured graph stays valid as the context grows.
   static const bool no_single = getenv("UMB_ATTN_SPLIT") != nullptr;
-  const int KBK = 2048;
+  // Keys per span.  Wide trees fill the chip with (kv head, query tile) pairs and take 2048-key spans; a NARROW launch (a
+  // draft level or a static-tree verify: 8 ... 56 blocks) walks a long context on that many CUs -- 70B, T = 13, context 1.6 k:
+  // 56 blocks x 786 KB of K / V^T each -- so its spans are 512 keys (round 4): up to Lmax / 512 times the blocks once the
+  // context is long, nothing changes below 512 keys (one live span, no merge; the other spans' blocks exit at once).
+  // Shape-only (T, Lmax), so a captured graph stays valid as the context grows.  UMB_ATTN_KBK: experiments.
+  static const int kbk_env = getenv("UMB_ATTN_KBK") ? atoi(getenv("UMB_ATTN_KBK")) : 0;
+  static const int one_env = getenv("UMB_ATTN_ONE") ? atoi(getenv("UMB_ATTN_ONE")) : 0;
+  int KBK = 2048, single_max = 2048;
+  if (counters && Hkv * nqt < 256) {
+    KBK = kbk_env >= 256 && kbk_env % 256 == 0 ? kbk_env : 512;
+    while ((Lmax + KBK - 1) / KBK > max_splits && KBK < 2048) KBK *= 2;
+    // one span up to 1024 keys: at 512-600 keys two spans measured +2 us per launch, at 1.6 k keys four spans -5.8 us
+    single_max = one_env > 0 ? one_env : 1024;
+    if (single_max < KBK) single_max = KBK;
+  }
   const int spans = (Lmax + KBK - 1) / KBK;
   if ((counters || spans == 1) && nqt <= 65535 && spans <= max_splits && !no_single) {
     // Waves per (kv head, query tile): eight while the tiles are few (narrow trees: the keys of a tile are spread over
@@ -545,7 +562,8 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
 #define ATT1N_(DD, NWV, NQV)                                                                                      \
   hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV, NQV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache, \
                      (const u16*)vt_cache, prefix_len, T, Hq, Hkv, Lmax, mask_words, n_mask_keys,                   \
-                     (const unsigned long long*)mask_bits, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt)
+                     (const unsigned long long*)mask_bits, scale, (u16*)out, KBK, (float*)po, (float*)pml, counters, out_fm_tt, \
+                     single_max)
 #define ATT1_(DD)                                                                                                 \
   if (nw == 1 && nq == 2) { ATT1N_(DD, 1, 2); } else if (nw == 1) { ATT1N_(DD, 1, 1); }                            \
   else if (nw == 2 && nq == 2) { ATT1N_(DD, 2, 2); } else if (nw == 2) { ATT1N_(DD, 2, 1); }                       \
