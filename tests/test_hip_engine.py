@@ -204,6 +204,32 @@ def test_dynamic_reference_config_tree_shapes(dev, width, num_beams, depth, awq)
     assert outs[0] == outs[1] and len(outs[0]) >= 24
 
 
+@pytest.mark.parametrize("kind", ["static", "dynamic"])
+def test_long_context_crosses_the_attention_span_switch(dev, kind):
+    """A 1000-token prompt and 60+ new tokens: the context passes 1024 keys inside the request, where the narrow tree-attention
+    launches (draft levels, static verify) switch from one span to 512-key spans merged by the last-arriving block -- inside
+    the captured iteration graph, whose geometry must stay valid across the switch.  Every token is an arg-max of the fp32
+    oracle and graph == eager."""
+    from hip_helpers import check_greedy, dynamic_engine, static_engine
+    dtype = torch.float16
+    vocab = G["target_cfg"]["vocab_size"]
+    g = torch.Generator().manual_seed(77)
+    prompt = torch.randint(6, vocab, (1000,), generator=g).tolist()
+    outs = []
+    for graph in (True, False):
+        if kind == "static":
+            eng, sd = static_engine(G, dev, dtype, self_draft=True, max_length=2048, hip_graph=graph)
+        else:
+            eng, sd = dynamic_engine(G, dev, dtype, self_draft=True, width=8, num_beams=8, depth=4, max_length=2048,
+                                     hip_graph=graph)
+        out = eng.generate(input_ids=prompt, max_new_tokens=72)
+        outs.append(out["generated_tokens"])
+        del eng
+    assert outs[0] == outs[1]
+    assert len(outs[0]) >= 60                        # 1000 + 60 > 1024: both regimes ran
+    check_greedy(G, sd, prompt, outs[0], dtype, mask_first_eos=(3, 5) if kind == "dynamic" else None)
+
+
 def test_stochastic_sampling_support(dev):
     """temperature > 0: sampled tokens stay inside the top-k / top-p support of the oracle's filtered
     target distribution (distributional parity only -- RNG streams differ)."""
