@@ -254,6 +254,17 @@ static int layer_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
 
 static int head_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int ssq_groups, hipStream_t st) {
   if (s->head_from >= s->T) return UMB_OK;
+  // Every row wants logits (a dynamic or static draft level) and the head runs unsplit: the LDS-shared kernel of gemm.hip reads
+  // the same FM activations and sums of squares (round 4: 1B head at 16 rows 116 -> 9x us; the whole-K kernel re-reads the
+  // activations once per wave).  UMB_LL_HEAD=ll: the whole-K kernel (A/B).  Shape-only + head_from, so batch invariance is kept.
+  static const char* env = getenv("UMB_LL_HEAD");
+  if (!(env && env[0] == 'l') && s->head_from == 0 && m->lm_head.S == 1 && !m->lm_head.awq && ssq_groups % 4 == 0 &&
+      ws->ssq_stride % 4 == 0) {
+    UmbGemmFused fs = {};
+    fs.ssq_in = ws->ssq; fs.ssq_groups = ssq_groups; fs.pad0 = ws->ssq_stride; fs.ssq_dim = (float)m->H; fs.eps = m->eps;
+    fs.pad1 = 1;                                            // x in FM layout
+    return lin(m->lm_head, ws->hw, m->H, ws->logits, s->T, m->dtype, st, /*EPI_ROUND*/1, &fs);
+  }
   UmbGemmLL fh = {};
   fh.row_from = s->head_from; fh.round_out = 1;
   fh.ssq_in = ws->ssq; fh.ssq_groups = ssq_groups; fh.ssq_in_stride = ws->ssq_stride; fh.ssq_dim = (float)m->H; fh.eps = m->eps;
