@@ -542,8 +542,9 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
   if (counters && Hkv * nqt < 256) {
     KBK = kbk_env >= 256 && kbk_env % 256 == 0 ? kbk_env : 512;
     while ((Lmax + KBK - 1) / KBK > max_splits && KBK < 2048) KBK *= 2;
-    // one span up to 1024 keys: at 512-600 keys two spans measured +2 us per launch, at 1.6 k keys four spans -5.8 us
-    single_max = one_env > 0 ? one_env : 1024;
+    // one span up to 768 keys: at 512-640 keys two spans measured +2 us per launch, at 1.6 k keys four spans -5.8 us; the
+    // headline engine at 600 / 800 / 1000-token prompts: 13.09 / 13.11 / 13.17 ms (512), 12.89 / 13.07 / 13.17 (768), 12.91 / 13.17 / 13.20 (1024)
+    single_max = one_env > 0 ? one_env : 768;
     if (single_max < KBK) single_max = KBK;
   }
   const int spans = (Lmax + KBK - 1) / KBK;
