@@ -23,8 +23,17 @@
 extern "C" {
 #endif
 
-/* Every V^T cache (vt_cache arguments below) has rows of Lmax + UMB_VT_PAD elements: with a power-of-two row
- * stride the 16 d-rows one MFMA fragment load touches fall on one memory channel. */
+/* KV cache layout (k_cache / vt_cache arguments below).  Per (layer, kv head) one slab: K of Lmax * D elements, V^T of
+ * D * (Lmax + UMB_VT_PAD) elements (the first Lmax * D are used; the stride is kept from the earlier row-padded form),
+ * Lmax a multiple of 32.  Inside a slab the elements are in MFMA FRAGMENT order, so that every load instruction of the
+ * tree-attention kernels is one contiguous KiB:
+ *   K  (key p, feature d): tile = p / 32, kk = p % 32, s = (kk / 4) % 2, j = 4 (kk / 8) + kk % 4
+ *        offset = ((((tile * 2 + s) * (D / 32) + d / 32) * 64 + ((d / 8) % 4) * 16 + j) * 8 + d % 8
+ *   V^T (feature d, key p): offset = (((p / 32) * (D / 16) + d / 16) * 64 + ((p / 8) % 4) * 16 + d % 16) * 8 + p % 8
+ * (umbrella_amd/csrc/common.h kc_off / vt_off; Python mirror with converters: umbrella_amd/attn/cache.py).  Callers never
+ * index the caches themselves: umb_reduce_qkv_rope* / umb_gemm_fused (epi 3) / umb_gemm_ll (epi 3) / umb_gemv (epi 3) /
+ * umb_kv_append write keys, umb_kv_compact moves them, umb_tree_attn* reads them.  The reference's layouts
+ * (umbrella/attn/cache.py:5-96 [L, Lmax, Hkv, D], :98-192 [L, Hkv, Lmax, D]) are what the converters speak. */
 #ifndef UMB_VT_PAD
 #define UMB_VT_PAD 32
 #endif
@@ -148,7 +157,7 @@ int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const voi
 int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
  * + KV_Cache.update_kv_cache (umbrella/attn/cache.py:53-65) at slots slot[t].
- * K cache [Hkv][Lmax][D]; V cache transposed [Hkv][D][Lmax + UMB_VT_PAD] (layer base pointers).
+ * K / V^T caches: layer base pointers, one fragment-ordered slab per kv head (layout note at the top of this file).
  * paired != 0: the q/k rows of the linear were packed as RoPE partner pairs (repack mode 2).
  * bias: NULL or the fused [q|k|v] projection bias [(Hq + 2 Hkv) D] in the model dtype, HF feature order
  * (Qwen2: umbrella/models/qwen.py:94-96). */
@@ -170,7 +179,7 @@ int umb_reduce_qkv_rope2(const void* partial, int S, int T, int Hq, int Hkv, int
 int umb_rope_inplace(void* q, void* k, const void* cosT, const void* sinT, const int* pos, int T, int Hq, int Hkv,
                      int D, int layout, int dtype, umb_stream_t stream);
 /* KV_Cache.update_kv_cache / StaticKV_Cache index_copy_ (umbrella/attn/cache.py:53-65, 155-156): k, v [T][Hkv][D]
- * 16-bit -> K cache [Hkv][Lmax][D] at rows slot[t], V cache transposed [Hkv][D][Lmax + UMB_VT_PAD] at columns slot[t]
+ * 16-bit -> key slot[t] of the K and V^T caches (fragment-ordered slabs, layout note at the top of this file)
  * (layer base pointers).  Slots outside [0, Lmax) are dropped. */
 int umb_kv_append(void* k_cache, void* vt_cache, const void* k, const void* v, const int* slot, int T, int Hkv, int D,
                   int Lmax, int dtype, umb_stream_t stream);
@@ -291,8 +300,8 @@ typedef struct UmbModel {
   const void* final_norm;
   const void* rope_cos;             /* [Lmax][D] model dtype (umbrella/models/llama.py:48-60) */
   const void* rope_sin;
-  void* k_cache;                    /* [L][Hkv][Lmax][D] */
-  void* vt_cache;                   /* [L][Hkv][D][Lmax + UMB_VT_PAD] */
+  void* k_cache;                    /* [L][Hkv] slabs of Lmax * D elements, fragment order (note at the top) */
+  void* vt_cache;                   /* [L][Hkv] slabs of D * (Lmax + UMB_VT_PAD) elements, fragment order */
   const UmbLayer* layers;           /* host array, L entries */
 } UmbModel;
 

@@ -64,7 +64,8 @@ def test_gemm_plan2_balances_whole_rounds(lib):
         return tuple(x.value for x in v)
     R, S, tb, srow = plan2(57344, 8192, 1, 1)
     assert (R, S, tb, srow) == (2, 1, 14 | 0x80, 0) and (57344 // 16) // 14 == 256     # one 8-wave block of 14 tiles per CU
-    assert plan2(28672, 4096, 1, 1) == (2, 1, 7, 0)                      # 8B-AWQ gate/up: 256 blocks of 7 tiles
+    # 8B gate/up (1792 n-tiles = 256 x 7), int4 or dense: one 8-wave block per CU, one tile per wave (round 4)
+    assert plan2(28672, 4096, 1, 1) == (1, 1, 7 | 0x80, 0) and plan2(28672, 4096, 0, 1) == (1, 1, 7 | 0x80, 0)
     assert plan2(8192, 8192, 1) == (2, 8, 0, 0)                          # 70B o: the runtime's row-reduce rule caps S at 4
     assert plan2(8192, 28672, 1) == (2, 8, 0, 0)                         # 70B down: 64 x 8 = 512 blocks already
     assert plan2(10240, 8192, 1)[0] == 2 and plan2(10240, 8192, 1)[2] == 0

@@ -6,6 +6,8 @@ weights (q / K / V^T contents, up to the fp32 accumulation order); bitwise batch
 import pytest
 import torch
 
+from umbrella_amd.attn.cache import k_from_frag, vt_from_frag      # semantic views of the fragment-ordered KV caches
+
 pytestmark = pytest.mark.gpu
 
 
@@ -145,8 +147,9 @@ def test_gemv_qkv_epilogue_matches_lowlat(dev, dtype, T, bias):
         assert float((a_.float() - b_.float()).abs().max()) <= 2 * _ulp(dtype) * scale
     free = torch.ones(Lmax, dtype=torch.bool, device=dev)
     free[slot.long()] = False
-    assert float(k2[:, free].abs().max()) == 0.0 and float(v2[:, :, :Lmax][:, :, free].abs().max()) == 0.0
-    assert float(k2[:, ~free].abs().max()) > 0
+    k2s, v2s = k_from_frag(k2), vt_from_frag(v2)              # semantic views of the fragment-ordered caches
+    assert float(k2s[:, free].abs().max()) == 0.0 and float(v2s[:, :, :Lmax][:, :, free].abs().max()) == 0.0
+    assert float(k2s[:, ~free].abs().max()) > 0
 
 
 def test_gemv_batch_invariance(dev):

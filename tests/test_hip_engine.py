@@ -302,7 +302,7 @@ def test_draft_lookback_matches_reference_schedule(dev, kind, monkeypatch):
             accepts.append(eng.last_accept)
         n = eng.num_nodes
         kv = eng.draft_model.kv_cache
-        res[lb] = (eng.tokens[:n + 1].tolist(), accepts, kv.k[:, :, :n].float().cpu(), kv.vt[:, :, :, :n].float().cpu())
+        res[lb] = (eng.tokens[:n + 1].tolist(), accepts, kv.k_rows(range(n)).float().cpu(), kv.v_rows(range(n)).float().cpu())
     assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]
     for a, b in zip(res["1"][2:], res["0"][2:]):
         assert (a - b).abs().max() <= 2e-2 * b.abs().max()       # same keys up to attention summation order

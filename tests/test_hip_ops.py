@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ops as O                                     # noqa: E402
-from umbrella_amd.attn.cache import VT_PAD                      # noqa: E402
+from umbrella_amd.attn.cache import VT_PAD, k_from_frag, k_to_frag, vt_from_frag, vt_to_frag     # noqa: E402
+# The caches are stored in MFMA fragment order (umbrella_amd/attn/cache.py); tests build and read them through these views.
 
 
 @pytest.fixture(scope="module")
@@ -157,11 +158,12 @@ def test_qkv_rope_kv_append(dev, dtype):
     qe, ke = O.apply_rope(qr, kr, cos, sin, pos.long())
     eps = torch.finfo(dtype).eps
     assert (q.cpu().float() - qe.float()).abs().max() <= 2 * eps * qe.float().abs().max()
-    kgot = kc.cpu()[:, 20:27].permute(1, 0, 2)
+    kc, vt = k_from_frag(kc.cpu()), vt_from_frag(vt.cpu())
+    kgot = kc[:, 20:27].permute(1, 0, 2)
     assert (kgot.float() - ke.float()).abs().max() <= 2 * eps * ke.float().abs().max()
-    vgot = vt.cpu()[:, :, 20:27].permute(2, 0, 1)
+    vgot = vt[:, :, 20:27].permute(2, 0, 1)
     assert torch.equal(vgot, vr)
-    assert kc.cpu()[:, :20].abs().max() == 0 and vt.cpu()[:, :, 27:].abs().max() == 0
+    assert kc[:, :20].abs().max() == 0 and vt[:, :, 27:].abs().max() == 0
 
 
 def _tree_mask(T, rs):
@@ -207,7 +209,8 @@ def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix, path):
     vt[:, :, :S] = v.permute(1, 2, 0)
     # stale garbage after the valid region must be ignored
     kc[:, S:S + 40] = 7.0
-    vt[:, :, S:S + 40] = -9.0
+    vt[:, :, S:min(S + 40, Lmax)] = -9.0
+    kc, vt = k_to_frag(kc), vt_to_frag(vt)
     bits = pack_mask_bits(tm).to(dev)
     out = torch.empty(T, Hq, D, dtype=dtype, device=dev)
     po = torch.empty(splits * T * Hq * D, dtype=torch.float32, device=dev)
@@ -263,6 +266,7 @@ def test_tree_attention_wide(dev, dtype, T, prefix, Lmax, kind, Hq, Hkv):
     vt = torch.zeros(Hkv, D, Lmax + VT_PAD, dtype=dtype)
     kc[:, :S] = k.permute(1, 0, 2)
     vt[:, :, :S] = v.permute(1, 2, 0)
+    kc, vt = k_to_frag(kc), vt_to_frag(vt)
     bits = pack_mask_bits(tm).to(dev)
     spans = (Lmax + 2047) // 2048
     out = torch.empty(T, Hq, D, dtype=dtype, device=dev)
@@ -523,21 +527,25 @@ def test_kv_compaction(dev, D):
     L, Hkv, Lmax = 3, 2, 64
     c = TreeKVCache(L, Hkv, D, Lmax, dev, torch.bfloat16)
     g = torch.Generator().manual_seed(9)
-    c.k.copy_(torch.randn(c.k.shape, generator=g)); c.vt.copy_(torch.randn(c.vt.shape, generator=g))
-    k0, v0 = c.k.clone(), c.vt.clone()
+    # semantic contents (key-major K, feature-major V^T); the cache stores them in fragment order
+    k0 = torch.randn(c.k.shape, generator=g).to(torch.bfloat16)
+    v0 = torch.randn(c.vt.shape, generator=g).to(torch.bfloat16)
+    v0[..., Lmax:] = 0
+    c.k.copy_(k_to_frag(k0)); c.vt.copy_(vt_to_frag(v0))
     n_old, path = 20, [0, 2, 5, 11]
     res = torch.tensor([len(path), 0, 0, n_old + len(path), len(path), 0, 0, 0], dtype=torch.int32, device=dev)
     c.compact(res, torch.tensor(path + [0] * 4, dtype=torch.int32, device=dev), 8)
     ke, ve = k0.clone(), v0.clone()
-    idx = torch.tensor(path, device=dev) + n_old
+    idx = torch.tensor(path) + n_old
     ke[:, :, n_old:n_old + 4] = k0[:, :, idx]
     ve[:, :, :, n_old:n_old + 4] = v0[:, :, :, idx]
-    assert torch.equal(c.k, ke) and torch.equal(c.vt, ve)
+    assert torch.equal(k_from_frag(c.k.cpu()), ke) and torch.equal(vt_from_frag(c.vt.cpu()), ve)
     # reference-signature gather gives the same result
     c2 = TreeKVCache(L, Hkv, D, Lmax, dev, torch.bfloat16)
-    c2.k.copy_(k0); c2.vt.copy_(v0)
-    c2.gather_kv_incremental(idx, n_old)
-    assert torch.equal(c2.k, ke) and torch.equal(c2.vt, ve) and c2.kv_offset == n_old + 4
+    c2.k.copy_(k_to_frag(k0)); c2.vt.copy_(vt_to_frag(v0))
+    c2.gather_kv_incremental(idx.to(dev), n_old)
+    assert torch.equal(c2.k, c.k) and torch.equal(c2.vt, c.vt) and c2.kv_offset == n_old + 4
+    assert torch.equal(c2.k_rows(idx + 0)[:, :, 0].cpu(), k0[:, :, n_old]) and torch.equal(c2.v_rows([n_old + 1]).cpu()[:, :, 0], v0[:, :, :, n_old + 2])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -652,9 +660,9 @@ def test_gemm_fused_qkv_epilogue(dev, dtype, T, awq):
     eps = torch.finfo(dtype).eps
     tol = 6 * eps
     assert (qo.cpu().float() - qe.float()).abs().max() <= tol * qe.float().abs().max()
-    kg = kc.cpu()[:, slot.long()].permute(1, 0, 2)
+    kg = k_from_frag(kc.cpu())[:, slot.long()].permute(1, 0, 2)
     assert (kg.float() - ke.float()).abs().max() <= tol * ke.float().abs().max()
-    vg = vt.cpu()[:, :, slot.long()].permute(2, 0, 1)
+    vg = vt_from_frag(vt.cpu())[:, :, slot.long()].permute(2, 0, 1)
     assert (vg.float() - vr.float()).abs().max() <= tol * vr.float().abs().max()
     assert int(counters.abs().sum()) == 0
 
@@ -817,9 +825,9 @@ def test_kv_append_then_attention(dev, dtype):
     for t in range(T - 1):
         kref[:, int(slot[t])] = k[t]
         vref[:, int(slot[t])] = v[t]
-    assert torch.equal(kc.cpu(), kref)
-    assert torch.equal(vt.cpu()[:, :, :Lmax], vref.permute(0, 2, 1))
-    assert float(vt[:, :, Lmax:].abs().max()) == 0.0
+    assert torch.equal(k_from_frag(kc.cpu()), kref)
+    assert torch.equal(vt_from_frag(vt.cpu())[:, :, :Lmax], vref.permute(0, 2, 1))
+    assert float(vt.view(Hkv, -1)[:, Lmax * D:].abs().max()) == 0.0          # nothing lands past the Lmax D fragment region
 
 
 def test_h2d_layer_event_ordered(dev):

@@ -12,6 +12,8 @@ import ctypes as C
 import pytest
 import torch
 
+from umbrella_amd.attn.cache import k_from_frag, vt_from_frag      # semantic views of the fragment-ordered KV caches
+
 from oracle import ops as O
 
 pytestmark = pytest.mark.gpu
@@ -229,8 +231,9 @@ def test_ll_qkv_epilogue_matches_split_path(dev, dtype, T, bias):
         assert float((a_.float() - b_.float()).abs().max()) <= 2 * ulp * scale, (float((a_.float() - b_.float()).abs().max()), scale)
     free = torch.ones(Lmax, dtype=torch.bool, device=dev)
     free[slot.long()] = False
-    assert float(k2[:, free].abs().max()) == 0.0 and float(v2[:, :, :Lmax][:, :, free].abs().max()) == 0.0   # only slot[t] written
-    assert float(k2[:, ~free].abs().max()) > 0
+    k2s, v2s = k_from_frag(k2), vt_from_frag(v2)              # semantic views of the fragment-ordered caches
+    assert float(k2s[:, free].abs().max()) == 0.0 and float(v2s[:, :, :Lmax][:, :, free].abs().max()) == 0.0   # only slot[t] written
+    assert float(k2s[:, ~free].abs().max()) > 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -70,10 +70,9 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int key = k0 + (j >> 2) * 8 + s * 4 + (j & 3);
-        const u16* kp = kbase + (long)key * D + gq * 8;
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds)
-          ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
+        for (int ds = 0; ds < DS; ++ds)        // fragment order (common.h kc_off): one contiguous KiB per load
+          ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kbase + ((long)((k0 >> 5) * 2 * DS + s * DS + ds) * 64 + lane) * 8) : zero4;
       }
     };
     auto tile = [&](int k0, const u32x4 (&ak)[2][DS]) {
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void tree_attn_kernel(const u16* __restrict__ 
       u32x4 av[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
-        av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * LV + k0 + gq * 8);
+        av[dt] = *reinterpret_cast<const u32x4*>(vbase + ((long)((k0 >> 5) * DT + dt) * 64 + lane) * 8);
       f32x4 st[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -208,15 +207,15 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
   const bool spec = kstart + 32 <= Lmax;
   u32x4 ka[2][DS], kb2[2][DS], va[DT], vb[DT];
   if (spec) {
+    // fragment order (common.h kc_off / vt_off): each of the 2 DS + DT loads of a tile is one contiguous KiB
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const u16* kp = kc + ((long)blockIdx.x * Lmax + kstart + (j >> 2) * 8 + s * 4 + (j & 3)) * D + gq * 8;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int ds = 0; ds < DS; ++ds) ka[s][ds] = *reinterpret_cast<const u32x4*>(kp + ds * 32);
-    }
-    const u16* vp = vt + (long)blockIdx.x * D * VT_LD(Lmax) + kstart + gq * 8;
+      for (int ds = 0; ds < DS; ++ds)
+        ka[s][ds] = *reinterpret_cast<const u32x4*>(kc + (long)blockIdx.x * Lmax * D + ((long)((kstart >> 5) * 2 * DS + s * DS + ds) * 64 + lane) * 8);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) va[dt] = *reinterpret_cast<const u32x4*>(vp + (long)(dt * 16 + j) * VT_LD(Lmax));
+    for (int dt = 0; dt < DT; ++dt)
+      va[dt] = *reinterpret_cast<const u32x4*>(vt + (long)blockIdx.x * D * VT_LD(Lmax) + ((long)((kstart >> 5) * DT + dt) * 64 + lane) * 8);
   }
   const int prefix = *prefix_p;
   const int kv_end = prefix + n_mask_keys;
@@ -272,10 +271,9 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int key = k0 + (j >> 2) * 8 + s * 4 + (j & 3);
-      const u16* kp = kbase + (long)key * D + gq * 8;
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds)
-        ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kp + ds * 32) : zero4;
+        ak[s][ds] = (key < k_hi) ? *reinterpret_cast<const u32x4*>(kbase + ((long)((k0 >> 5) * 2 * DS + s * DS + ds) * 64 + lane) * 8) : zero4;
     }
   };
   // A = V^T tiles: lane (i = j -> d row, gq) holds keys k0 + gq*8 .. +7 (16 B); loaded one tile ahead like K.
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, NQ > 1 ? 1 : 2) void tree_attn1_kernel(con
   auto load_v = [&](int k0, u32x4 (&av)[DT]) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
-      av[dt] = *reinterpret_cast<const u32x4*>(vbase + (long)(dt * 16 + j) * LV + k0 + gq * 8);
+      av[dt] = *reinterpret_cast<const u32x4*>(vbase + ((long)((k0 >> 5) * DT + dt) * 64 + lane) * 8);
   };
   auto tile = [&](int k0, const u32x4 (&ak)[2][DS], const u32x4 (&av)[DT]) {
 #pragma unroll
@@ -523,7 +521,7 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
                               const int* prefix_len, const void* mask_bits, int mask_words, int n_mask_keys, int T,
                               int Hq, int Hkv, int D, int Lmax, int chunk, int max_splits, float scale,
                               unsigned* counters, int out_fm_tt, int dtype, hipStream_t st) {
-  if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 8 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
+  if (T < 1 || Hq % Hkv || chunk % 32 || Lmax % 32 || (D != 32 && D != 64 && D != 128)) return UMB_EINVAL;
   if (out_fm_tt && (out_fm_tt * 16 < T || (Hq * D) % 32)) return UMB_EINVAL;
   const int nrows = T * (Hq / Hkv);
   const int nqt = (nrows + 15) / 16;

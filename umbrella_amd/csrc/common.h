@@ -10,6 +10,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- KV cache element order inside one (layer, kv head) slab: MFMA FRAGMENT order (round 4).  The tree-attention kernels
+// consume K as the A operand of S^T = K Q^T (16 keys x 32 d per instruction, lane (j, g) = key j, d 8g .. 8g+7) and V^T as the A
+// operand of O^T = V^T P^T (16 d x 32 keys, lane (j, g) = d row j, keys 8g .. 8g+7).  A 32-key tile is stored as exactly those
+// fragments -- K: 2 (key halves) x D/32 fragments, V^T: D/16 fragments, 1 KiB (64 lanes x 16 B) each, contiguous -- so every load
+// instruction of the attention kernels reads ONE contiguous KiB instead of 16 rows x 64 B (profiles/r04_attn_frag_probe.txt:
+// T = 13 verify 6.8 -> 5.2 us at 100 keys, 13.5 -> 10.1 at 1000; T = 257 24.2 -> 17.2).  Writers (q/k/v epilogues, kv append,
+// compaction) address single elements through these two functions; slab strides are unchanged (K: Lmax D, V^T: D VT_LD(Lmax)
+// elements per kv head, Lmax a multiple of 32).  Python mirror: umbrella_amd/attn/cache.py.
+//   key p, feature d of K   : tile p / 32, key-in-tile kk = p % 32 -> half s = (kk / 4) % 2, lane row j = 4 (kk / 8) + kk % 4
+__host__ __device__ __forceinline__ long kc_off(int p, int d, int D) {
+  const int kk = p & 31;
+  const int s = (kk >> 2) & 1, j = ((kk >> 3) << 2) | (kk & 3);
+  return ((((long)(p >> 5) * 2 + s) * (D >> 5) + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + j) * 8 + (d & 7);
+}
+//   feature d, key p of V^T : tile p / 32, fragment d / 16, lane (j = d % 16, g = (p % 32) / 8), element p % 8
+__host__ __device__ __forceinline__ long vt_off(int d, int p, int D) {
+  return (((long)(p >> 5) * (D >> 4) + (d >> 4)) * 64 + ((p >> 3) & 3) * 16 + (d & 15)) * 8 + (p & 7);
+}
+
 #define UMB_OK 0
 #define UMB_EINVAL (-22)
 #define UMB_EHIP (-5)

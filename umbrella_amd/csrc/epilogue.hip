@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void reduce_silu_mul_kernel(const float* __res
 
 // ---- QKV reduce + RoPE + KV append.  One block per (token, head) with D/2 active pairs.
 // partial row layout: [q (Hq*D) | k (Hkv*D) | v (Hkv*D)]
-// K cache: [Hkv][Lmax][D] ; V cache transposed: [Hkv][D][Lmax + UMB_VT_PAD]   (layer base pointers)
+// K cache / V^T cache: per kv head a slab of Lmax D / D (Lmax + UMB_VT_PAD) elements in MFMA fragment order (common.h kc_off / vt_off)
 template <typename P>
 __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __restrict__ part, int S, int T, int Hq,
                                                              int Hkv, int D, int Lmax, const int* __restrict__ pos,
@@ -256,14 +256,13 @@ __global__ __launch_bounds__(64) void reduce_qkv_rope_kernel(const float* __rest
         u16* qo = q_out + ((long)t * Hq + head) * D;
         qo[d] = P::from_f(o0); qo[d + half] = P::from_f(o1);
       } else {
-        u16* ko = kc + ((long)(head - Hq) * Lmax + sl) * D;
-        ko[d] = P::from_f(o0); ko[d + half] = P::from_f(o1);
+        u16* ko = kc + (long)(head - Hq) * Lmax * D;            // fragment order inside the head's slab (common.h)
+        ko[kc_off(sl, d, D)] = P::from_f(o0); ko[kc_off(sl, d + half, D)] = P::from_f(o1);
       }
     } else {
-      const long LV = VT_LD(Lmax);
-      u16* vo = vt + (long)(head - Hq - Hkv) * D * LV + sl;
-      vo[(long)d * LV] = P::from_f(a);
-      vo[(long)(d + half) * LV] = P::from_f(b);
+      u16* vo = vt + (long)(head - Hq - Hkv) * D * VT_LD(Lmax);
+      vo[vt_off(d, sl, D)] = P::from_f(a);
+      vo[vt_off(d + half, sl, D)] = P::from_f(b);
     }
   }
 }
@@ -340,21 +339,20 @@ __global__ __launch_bounds__(64) void rope_inplace_kernel(u16* __restrict__ q, u
   }
 }
 
-// k / v [T][Hkv][D] -> K cache [Hkv][Lmax][D] row slot[t], V^T cache [Hkv][D][Lmax + UMB_VT_PAD] column slot[t]
+// k / v [T][Hkv][D] -> key slot[t] of the K cache and of the V^T cache (fragment order, common.h)
 __global__ __launch_bounds__(64) void kv_append_kernel(u16* __restrict__ kc, u16* __restrict__ vt,
                                                        const u16* __restrict__ k, const u16* __restrict__ v,
                                                        const int* __restrict__ slot, int Hkv, int D, int Lmax) {
   const int t = blockIdx.x, h = blockIdx.y;
   const int sl = slot[t];
   if (sl < 0 || sl >= Lmax) return;                               // a slot outside the cache is dropped, never written
-  const long LV = VT_LD(Lmax);
   const u16* ks = k + ((long)t * Hkv + h) * D;
   const u16* vs = v + ((long)t * Hkv + h) * D;
-  u16* kd = kc + ((long)h * Lmax + sl) * D;
-  u16* vd = vt + (long)h * D * LV + sl;
+  u16* kd = kc + (long)h * Lmax * D;                              // fragment order inside the head's slab (common.h)
+  u16* vd = vt + (long)h * D * VT_LD(Lmax);
   for (int d = threadIdx.x; d < D; d += 64) {
-    kd[d] = ks[d];
-    vd[(long)d * LV] = vs[d];
+    kd[kc_off(sl, d, D)] = ks[d];
+    vd[vt_off(d, sl, D)] = vs[d];
   }
 }
 
@@ -405,7 +403,7 @@ extern "C" int umb_reduce_qkv_rope2(const void* partial, int S, int T, int Hq, i
                                     const int* pos, const int* slot, const void* cosT, const void* sinT, void* q_out,
                                     void* k_cache, void* vt_cache, int paired, const void* bias, const float* ssq_in,
                                     int ssq_groups, int ssq_stride, float ssq_dim, float eps, int dtype, hipStream_t st) {
-  if (D % 2 || (ssq_in && (ssq_groups < 1 || ssq_stride < ssq_groups || ssq_dim <= 0.f))) return UMB_EINVAL;
+  if (D % 32 || Lmax % 32 || (ssq_in && (ssq_groups < 1 || ssq_stride < ssq_groups || ssq_dim <= 0.f))) return UMB_EINVAL;   // 32-key x 32-feature cache tiles
   DISPATCH_DTYPE(dtype, {
     hipLaunchKernelGGL((reduce_qkv_rope_kernel<P>), dim3(T, Hq + 2 * Hkv), dim3(64), 0, st, (const float*)partial, S, T,
                        Hq, Hkv, D, Lmax, pos, slot, (const u16*)cosT, (const u16*)sinT, (u16*)q_out, (u16*)k_cache,
@@ -451,7 +449,7 @@ extern "C" int umb_rope_inplace(void* q, void* k, const void* cosT, const void* 
 
 extern "C" int umb_kv_append(void* k_cache, void* vt_cache, const void* k, const void* v, const int* slot, int T,
                              int Hkv, int D, int Lmax, int dtype, hipStream_t st) {
-  if (T < 1 || Hkv < 1 || D < 1 || Lmax < 1 || (dtype != UMB_F16 && dtype != UMB_BF16)) return UMB_EINVAL;
+  if (T < 1 || Hkv < 1 || D < 32 || D % 32 || Lmax < 32 || Lmax % 32 || (dtype != UMB_F16 && dtype != UMB_BF16)) return UMB_EINVAL;
   hipLaunchKernelGGL(kv_append_kernel, dim3(T, Hkv), dim3(64), 0, st, (u16*)k_cache, (u16*)vt_cache, (const u16*)k,
                      (const u16*)v, slot, Hkv, D, Lmax);
   UMB_LAUNCH_CHECK();

@@ -670,15 +670,17 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
         const float lo1 = rnd<P>(mul_rnd<P>(a1, hi_f<P>(cl)) + mul_rnd<P>(-b1, hi_f<P>(sl_)));
         const float hi0 = rnd<P>(mul_rnd<P>(b0, lo_f<P>(ch)) + mul_rnd<P>(a0, lo_f<P>(sh)));
         const float hi1 = rnd<P>(mul_rnd<P>(b1, hi_f<P>(ch)) + mul_rnd<P>(a1, hi_f<P>(sh)));
-        u16* dst = (head < fx.Hq) ? fx.q_out + ((long)tok * fx.Hq + head) * D
-                                  : fx.kc + ((long)(head - fx.Hq) * fx.Lmax + sl) * D;
-        *reinterpret_cast<unsigned*>(dst + m) = pack2<P>(lo0, lo1);
-        *reinterpret_cast<unsigned*>(dst + m + half) = pack2<P>(hi0, hi1);
+        // q rows are row-major; the K / V^T caches are in fragment order inside a head's slab (common.h: m is even, so the
+        // pair (m, m + 1) stays one 4-byte store)
+        u16* dlo = (head < fx.Hq) ? fx.q_out + ((long)tok * fx.Hq + head) * D + m
+                                  : fx.kc + (long)(head - fx.Hq) * fx.Lmax * D + kc_off(sl, m, D);
+        u16* dhi = (head < fx.Hq) ? dlo + half : fx.kc + (long)(head - fx.Hq) * fx.Lmax * D + kc_off(sl, m + half, D);
+        *reinterpret_cast<unsigned*>(dlo) = pack2<P>(lo0, lo1);
+        *reinterpret_cast<unsigned*>(dhi) = pack2<P>(hi0, hi1);
       } else {
-        const long LV = VT_LD(fx.Lmax);
-        u16* dst = fx.vt + ((long)(head - fx.Hq - fx.Hkv) * D + dp) * LV + sl;
-        dst[0] = P::from_f(a0); dst[LV] = P::from_f(b0);
-        dst[2L * LV] = P::from_f(a1); dst[3L * LV] = P::from_f(b1);
+        u16* vb = fx.vt + (long)(head - fx.Hq - fx.Hkv) * D * VT_LD(fx.Lmax);
+        vb[vt_off(dp, sl, D)] = P::from_f(a0); vb[vt_off(dp + 1, sl, D)] = P::from_f(b0);
+        vb[vt_off(dp + 2, sl, D)] = P::from_f(a1); vb[vt_off(dp + 3, sl, D)] = P::from_f(b1);
       }
     }
   }
@@ -1423,13 +1425,15 @@ extern "C" void umb_gemm_plan2(int N, int K, int awq, int force_s1, int* R_out, 
     if (!no_w8 && awq && b8 % 256 != 0 && b14 == 256) tb = 14 | 0x80;
 
   }
-  // Round 4: a linear that the rules above leave with at most ONE 4-wave block per CU, and whose n-tiles are exactly 256 groups of
-  // 5 ... 8, runs as one 8-wave block per CU with one tile per wave (8B gate/up, dense or int4: 1792 tiles = 256 x 7).  Twice the
-  // waves per CU on the same bytes, one staged copy of the activations; same per-output summation order, so the bits do not
-  // change.  8B forward, dense at 5 / 31 rows 3.52 -> 3.46 / 3.90 -> 3.86 ms, int4 at 1 / 16 / 32 rows -2 / -1 / -1 %.
+  // Round 4: a linear that the rules above leave with at most ONE 4-wave block per CU (8B-AWQ gate/up: 256 blocks of 2 + 2 + 2 + 1
+  // tiles) or with a ragged round (8B dense gate/up: 448 four-tile blocks), and whose n-tiles are exactly 256 groups of 5 ... 8, runs as
+  // one 8-wave block per CU with one tile per wave (1792 tiles = 256 x 7).  Twice the waves per CU on the same bytes, one staged copy of
+  // the activations; same per-output summation order, so the bits do not change.  8B forward, dense at 5 / 31 rows 3.52 -> 3.46 /
+  // 3.90 -> 3.86 ms, int4 at 1 / 16 / 32 rows -2 / -1 / -1 %.
   if (!off && !no_w8 && !(tb & 0x80)) {
     const int per = tb ? tb : 4 * R;
-    if (((NT + per - 1) / per) * S <= 256)
+    const int cur = ((NT + per - 1) / per) * S;
+    if (cur <= 256 || (S == 1 && cur % 256 != 0))             // the ragged case only where it was measured (unsplit gate/up)
       for (int t8 = 8; t8 >= 5; --t8)
         if (NT % t8 == 0 && (NT / t8) * S == 256) { R = 1; tb = t8 | 0x80; break; }
   }

@@ -232,14 +232,20 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
           // slot_t is trusted here (the model runtime derives it from the engine's guarded state: HipEngine.step refuses
           // a tree that would pass max_length); a per-store range check costs this kernel 24 B of scratch per lane
           // (tests/test_abi.py guards that).  The stand-alone umb_kv_append is the range-checked form.
-          u16* dst = (head < a.Hq) ? a.q_out + ((long)t * a.Hq + head) * D : a.kc + ((long)(head - a.Hq) * a.Lmax + slot_t) * D;
-          dst[m] = P::from_f(lo0);
-          dst[m + half] = P::from_f(hi0);
+          // q rows are row-major; the K / V^T caches are in fragment order inside a head's slab (common.h)
+          if (head < a.Hq) {
+            u16* dst = a.q_out + ((long)t * a.Hq + head) * D;
+            dst[m] = P::from_f(lo0);
+            dst[m + half] = P::from_f(hi0);
+          } else {
+            u16* dst = a.kc + (long)(head - a.Hq) * a.Lmax * D;
+            dst[kc_off(slot_t, m, D)] = P::from_f(lo0);
+            dst[kc_off(slot_t, m + half, D)] = P::from_f(hi0);
+          }
         } else {
-          const long LV = VT_LD(a.Lmax);
-          u16* dst = a.vt + ((long)(head - a.Hq - a.Hkv) * D + dp) * LV + slot_t;
-          dst[0] = P::from_f(a0);
-          dst[LV] = P::from_f(b0);
+          u16* dst = a.vt + (long)(head - a.Hq - a.Hkv) * D * VT_LD(a.Lmax);
+          dst[vt_off(dp, slot_t, D)] = P::from_f(a0);
+          dst[vt_off(dp + 1, slot_t, D)] = P::from_f(b0);
         }
       }
     }

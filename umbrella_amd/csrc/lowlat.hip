@@ -408,15 +408,16 @@ __global__ __launch_bounds__(512, 2) void ll_gemm_kernel(const u32x4* __restrict
           const float lo1 = rnd<P>(mul_rnd<P>(a1, hi_f<P>(cl)) + mul_rnd<P>(-b1, hi_f<P>(sl_)));
           const float hi0 = rnd<P>(mul_rnd<P>(b0, lo_f<P>(ch)) + mul_rnd<P>(a0, lo_f<P>(sh)));
           const float hi1 = rnd<P>(mul_rnd<P>(b1, hi_f<P>(ch)) + mul_rnd<P>(a1, hi_f<P>(sh)));
-          u16* dst = (head < a.Hq) ? a.q_out + ((long)t * a.Hq + head) * D
-                                   : a.kc + ((long)(head - a.Hq) * a.Lmax + sl) * D;
-          *reinterpret_cast<unsigned*>(dst + m) = pack2<P>(lo0, lo1);
-          *reinterpret_cast<unsigned*>(dst + m + half) = pack2<P>(hi0, hi1);
+          // q rows are row-major; the K / V^T caches are in fragment order inside a head's slab (common.h; m is even)
+          u16* dlo = (head < a.Hq) ? a.q_out + ((long)t * a.Hq + head) * D + m
+                                   : a.kc + (long)(head - a.Hq) * a.Lmax * D + kc_off(sl, m, D);
+          u16* dhi = (head < a.Hq) ? dlo + half : a.kc + (long)(head - a.Hq) * a.Lmax * D + kc_off(sl, m + half, D);
+          *reinterpret_cast<unsigned*>(dlo) = pack2<P>(lo0, lo1);
+          *reinterpret_cast<unsigned*>(dhi) = pack2<P>(hi0, hi1);
         } else {
-          const long LV = VT_LD(a.Lmax);
-          u16* dst = a.vt + ((long)(head - a.Hq - a.Hkv) * D + dp) * LV + sl;
-          dst[0] = P::from_f(a0); dst[LV] = P::from_f(b0);
-          dst[2L * LV] = P::from_f(a1); dst[3L * LV] = P::from_f(b1);
+          u16* vb = a.vt + (long)(head - a.Hq - a.Hkv) * D * VT_LD(a.Lmax);
+          vb[vt_off(dp, sl, D)] = P::from_f(a0); vb[vt_off(dp + 1, sl, D)] = P::from_f(b0);
+          vb[vt_off(dp + 2, sl, D)] = P::from_f(a1); vb[vt_off(dp + 3, sl, D)] = P::from_f(b1);
         }
       }
     }

@@ -504,22 +504,21 @@ __global__ __launch_bounds__(256) void kv_compact_kernel(u16* __restrict__ kc, u
   if (keep <= 1) return;
   const int n_old = res[3] - res[0];
   const int h = blockIdx.x, layer = blockIdx.y;
-  u16* kb = kc + ((long)layer * Hkv + h) * Lmax * D;
-  const long LV = VT_LD(Lmax);
-  u16* vb = vt + ((long)layer * Hkv + h) * D * LV;
+  u16* kb = kc + ((long)layer * Hkv + h) * Lmax * D;        // fragment order inside the head's slab (common.h kc_off / vt_off)
+  u16* vb = vt + ((long)layer * Hkv + h) * D * VT_LD(Lmax);
   const int total = keep * D;
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e / D, d = e % D;
     const int src = n_old + path[i];
-    sk[e] = kb[(long)src * D + d];
-    sv[e] = vb[(long)d * LV + src];
+    sk[e] = kb[kc_off(src, d, D)];
+    sv[e] = vb[vt_off(d, src, D)];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < total; e += 256) {
     const int i = e / D, d = e % D;
     if (path[i] == i) continue;
-    kb[(long)(n_old + i) * D + d] = sk[e];
-    vb[(long)d * LV + n_old + i] = sv[e];
+    kb[kc_off(n_old + i, d, D)] = sk[e];
+    vb[vt_off(d, n_old + i, D)] = sv[e];
   }
 }
 
@@ -649,6 +648,7 @@ extern "C" int umb_accept_scan(const int* sampled, const int* parents, int* toke
 
 extern "C" int umb_kv_compact(void* k_cache, void* vt_cache, const int* res, const int* path, int L, int Hkv, int D,
                               int Lmax, int max_path, int dtype_unused, hipStream_t st) {
+  if (Lmax % 32) return UMB_EINVAL;                            // fragment-ordered slabs are tiled by 32 keys
   const size_t sm = (size_t)max_path * D * 2 * 2;
   const dim3 grid(Hkv, L), block(256);
   if (D == 128) hipLaunchKernelGGL((kv_compact_kernel<128>), grid, block, sm, st, (u16*)k_cache, (u16*)vt_cache, res, path, Hkv, Lmax, max_path);
