@@ -552,11 +552,13 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
     // so the per-block prologue and merge are paid 4x / 8x less often.
     static const int nw_env = getenv("UMB_ATTN_NW") ? atoi(getenv("UMB_ATTN_NW")) : 0;
     const int nblk = Hkv * nqt;
-    const int nw = nw_env ? nw_env : nblk >= 2048 ? 1 : nblk >= 512 ? 2 : 8;
-    // query tiles per block: two once the launch has a thousand (kv head, query tile) pairs (wide trees, prompt chunks):
-    // each K / V^T tile a wave pulls from L2 then feeds two query tiles (UMB_ATTN_NQ=1: the round-3 kernel, A/B)
+    const int nw = nw_env ? nw_env : nblk >= 1792 ? 1 : nblk >= 512 ? 2 : 8;   // fragment-ordered cache: T = 505 (2024 pairs) 31.8 (1) vs 35.1 (2) us, T = 385 (1544) 25.9 vs 24.4
     static const int nq_env = getenv("UMB_ATTN_NQ") ? atoi(getenv("UMB_ATTN_NQ")) : 0;
-    const int nq = (nw > 2 || nblk < 1536) ? 1 : nq_env ? (nq_env >= 2 ? 2 : 1) : 2;   // T = 257 (1032 pairs): 24.3 vs 25.4 us, stays at one
+    // On the row-major cache two query tiles per loaded K / V^T tile won 11-40 % from 1536 pairs up; on the fragment-ordered cache a
+    // tile costs 2 DS + DT coalesced KiB loads and the second query tile's registers (one wave per SIMD) cost more than they save:
+    // T = 769 52.3 (one) vs 64.7 us (two), T = 385 24.4 vs 31.8, causal 1024-token chunk at 1024 keys 137 vs 156
+    // (profiles/r04_attn_geometry_sweep.txt).  One tile per block; UMB_ATTN_NQ=2 keeps the other instantiation for experiments.
+    const int nq = (nw <= 2 && nq_env >= 2) ? 2 : 1;
     const dim3 grid1(Hkv, (nqt + nq - 1) / nq, spans), block1(64 * nw);
 #define ATT1N_(DD, NWV, NQV)                                                                                      \
   hipLaunchKernelGGL((tree_attn1_kernel<P, DD, NWV, NQV>), grid1, block1, 0, st, (const u16*)q, (const u16*)k_cache, \
