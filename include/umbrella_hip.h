@@ -150,9 +150,15 @@ int umb_embed_ll(void* h, const void* table, int H, int V, int Lmax, int T, cons
 /* ------------------------------------------------------------------ stand-alone epilogues (op-level API) */
 /* flashinfer.rmsnorm (umbrella/models/model_utils.py:54-64) */
 int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype, umb_stream_t stream);
+/* the same with the output in FM order (MFMA B-fragment order, [H/32][fm_tt token tiles][64 lanes][8]: what the GEMMs of a
+ * <= 64-row forward read as contiguous KiB fragments); fm_tt = 0: row-major, else 1 / 2 / 4 tiles of 16 rows (umb_ll_token_tiles) */
+int umb_rmsnorm_fm(void* out, const void* x, const void* w, float eps, int rows, int H, int fm_tt, int dtype, umb_stream_t stream);
 /* h = residual + sum_s partial ; xn = rmsnorm(h)*w   (llama.py:104-106,112-113 + next layer's :87) */
 int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
                              void* xn_out, const void* w, float eps, int dtype, umb_stream_t stream);
+/* the same with xn_out in FM order (xn_fm_tt as fm_tt of umb_rmsnorm_fm; h_out stays row-major) */
+int umb_reduce_residual_norm_fm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
+                                void* xn_out, const void* w, float eps, int xn_fm_tt, int dtype, umb_stream_t stream);
 /* act = silu(gate) * up  (llama.py:107-110); partial rows are [gate | up] */
 int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]

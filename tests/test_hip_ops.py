@@ -1,4 +1,5 @@
 """Kernel-level parity (GPU): every HIP op through the C ABI vs the CPU oracle / fp32 torch."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -105,6 +106,35 @@ def test_reduce_residual_norm_and_silu(dev, dtype):
     gate, up = part.sum(0)[:, :I].to(dtype), part.sum(0)[:, I:].to(dtype)
     aref = torch.nn.functional.silu(gate) * up
     assert (act.cpu().float() - aref.float()).abs().max() <= 4 * torch.finfo(dtype).eps * aref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,S,N", [(13, 4, 8192), (31, 8, 4096), (1, 2, 2048), (64, 13, 4096), (40, 9, 8192)])
+def test_fm_ordered_norm_outputs_equal_the_row_major_ones(dev, dtype, T, S, N):
+    """umb_rmsnorm_fm / umb_reduce_residual_norm_fm (the split schedule's <= 64-row forwards keep their GEMM operands in FM order):
+    the same bits as the row-major forms, at the FM positions (umb_from_fm converts back); h_out stays row-major."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(T + S)
+    dt = _lib.dtype_code(dtype)
+    tt = _lib.load().umb_ll_token_tiles(T)
+    part = torch.randn(S, T, N, generator=g).to(dev)
+    res = torch.randn(T, N, generator=g).to(dtype).to(dev)
+    w = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(dev)
+    h0, x0 = torch.empty(T, N, dtype=dtype, device=dev), torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_residual_norm", part, S, T, N, res, h0, x0, w, 1e-5, dt)
+    h1 = torch.empty(T, N, dtype=dtype, device=dev)
+    xfm = torch.zeros(tt * 16 * N, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_residual_norm_fm", part, S, T, N, res, h1, xfm, w, 1e-5, tt, dt)
+    back = torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_from_fm", back, xfm, T, N, dt)
+    assert torch.equal(h1, h0) and torch.equal(back, x0)
+    r0 = torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_rmsnorm", r0, h0, w, 1e-5, T, N, dt)
+    xfm.zero_()
+    _lib.call("umb_rmsnorm_fm", xfm, h0, w, 1e-5, T, N, tt, dt)
+    _lib.call("umb_from_fm", back, xfm, T, N, dt)
+    assert torch.equal(back, r0)
+    assert _lib.load().umb_rmsnorm_fm(None, None, None, C.c_float(1e-5), 17, N, 1, dt, None) == -22       # 17 rows do not fit one tile
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -127,7 +127,9 @@ SIGNATURES = {
     "umb_embed_ll": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "umb_tree_attn2": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "umb_rmsnorm": [_P, _P, _P, _F, _I, _I, _I, _P],
+    "umb_rmsnorm_fm": [_P, _P, _P, _F, _I, _I, _I, _I, _P],
     "umb_reduce_residual_norm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P],
+    "umb_reduce_residual_norm_fm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P],
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
     "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "umb_stream_read": [_P, C.c_size_t, _P, _P],

@@ -18,6 +18,11 @@
 // T = 13 verify 6.8 -> 5.2 us at 100 keys, 13.5 -> 10.1 at 1000; T = 257 24.2 -> 17.2).  Writers (q/k/v epilogues, kv append,
 // compaction) address single elements through these two functions; slab strides are unchanged (K: Lmax D, V^T: D VT_LD(Lmax)
 // elements per kv head, Lmax a multiple of 32).  Python mirror: umbrella_amd/attn/cache.py.
+// ---- activations in FM (MFMA B-fragment) order, [K/32][TT token tiles][64 lanes][8]: element offset of (token t, feature f).
+// One B fragment (16 tokens x 32 features) is one contiguous KiB (lowlat.hip header; umb_to_fm / umb_from_fm convert).
+__host__ __device__ __forceinline__ long fm_off(int t, int f, int TT) {
+  return ((((long)(f >> 5) * TT + (t >> 4)) * 64 + ((f >> 3) & 3) * 16 + (t & 15)) << 3) + (f & 7);
+}
 //   key p, feature d of K   : tile p / 32, key-in-tile kk = p % 32 -> half s = (kk / 4) % 2, lane row j = 4 (kk / 8) + kk % 4
 __host__ __device__ __forceinline__ long kc_off(int p, int d, int D) {
   const int kk = p & 31;

@@ -12,7 +12,8 @@
 // ---- plain RMSNorm over rows of 16-bit x (also the standalone umb_rmsnorm op)
 template <typename P>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(u16* __restrict__ out, const u16* __restrict__ x,
-                                                      const u16* __restrict__ w, float eps, int H) {
+                                                      const u16* __restrict__ w, float eps, int H, int fm_tt) {
+  // fm_tt > 0: out in FM order with fm_tt token tiles (the split schedule's GEMMs read coalesced KiB fragments, round 4)
   __shared__ float red[4];
   const int t = blockIdx.x;
   const u16* xr = x + (long)t * H;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(u16* __restrict__ out, con
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       o[e] = pack2<P>(lo_f<P>(v[e]) * inv * lo_f<P>(g[e]), hi_f<P>(v[e]) * inv * hi_f<P>(g[e]));
-    *reinterpret_cast<u32x4*>(out + (long)t * H + i) = o;
+    *reinterpret_cast<u32x4*>(out + (fm_tt ? fm_off(t, i, fm_tt) : (long)t * H + i)) = o;
   }
 }
 
@@ -56,7 +57,8 @@ template <typename P>
 __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float* __restrict__ part, int S, int T, int N,
                                                                     const u16* residual, u16* h_out,
                                                                     u16* __restrict__ xn_out,
-                                                                    const u16* __restrict__ w, float eps) {
+                                                                    const u16* __restrict__ w, float eps, int xn_fm_tt) {
+  // xn_fm_tt > 0: xn_out in FM order with that many token tiles (h_out stays row-major)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);            // 16 floats
   u16* row = reinterpret_cast<u16*>(smem + 64);           // N x u16
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
       uint2 o;
       o.x = pack2<P>(lo_f<P>(v.x) * inv * lo_f<P>(g.x), hi_f<P>(v.x) * inv * hi_f<P>(g.x));
       o.y = pack2<P>(lo_f<P>(v.y) * inv * lo_f<P>(g.y), hi_f<P>(v.y) * inv * hi_f<P>(g.y));
-      *reinterpret_cast<uint2*>(xn_out + (long)t * N + i) = o;
+      *reinterpret_cast<uint2*>(xn_out + (xn_fm_tt ? fm_off(t, i, xn_fm_tt) : (long)t * N + i)) = o;
     };
     if (ok0) norm(o0, g0, i0);
     if (ok1) norm(o1, g1, i1);
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
     uint2 o;
     o.x = pack2<P>(lo_f<P>(v.x) * inv * lo_f<P>(g.x), hi_f<P>(v.x) * inv * hi_f<P>(g.x));
     o.y = pack2<P>(lo_f<P>(v.y) * inv * lo_f<P>(g.y), hi_f<P>(v.y) * inv * hi_f<P>(g.y));
-    *reinterpret_cast<uint2*>(xn_out + (long)t * N + i) = o;
+    *reinterpret_cast<uint2*>(xn_out + (xn_fm_tt ? fm_off(t, i, xn_fm_tt) : (long)t * N + i)) = o;
   }
 }
 
@@ -366,11 +368,30 @@ __global__ __launch_bounds__(256) void sum_splits_kernel(float* __restrict__ par
 }
 
 // ------------------------------------------------------------------ C entry points
+// fm_tt: 0 = row-major out [rows][H]; 1 / 2 / 4 = out in FM order with that many 16-token tiles (rows <= 16 fm_tt, H % 32 == 0)
+extern "C" int umb_rmsnorm_fm(void* out, const void* x, const void* w, float eps, int rows, int H, int fm_tt, int dtype,
+                              hipStream_t st) {
+  if (H % 8 || rows < 1 || fm_tt < 0 || (fm_tt && (rows > 16 * fm_tt || H % 32))) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((rmsnorm_kernel<P>), dim3(rows), dim3(256), 0, st, (u16*)out, (const u16*)x, (const u16*)w, eps, H, fm_tt);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
 extern "C" int umb_rmsnorm(void* out, const void* x, const void* w, float eps, int rows, int H, int dtype,
                            hipStream_t st) {
-  if (H % 8 || rows < 1) return UMB_EINVAL;
+  return umb_rmsnorm_fm(out, x, w, eps, rows, H, 0, dtype, st);
+}
+
+// xn_fm_tt: as fm_tt above, for xn_out only
+extern "C" int umb_reduce_residual_norm_fm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
+                                           void* xn_out, const void* w, float eps, int xn_fm_tt, int dtype, hipStream_t st) {
+  if (N % 4 || T < 1 || xn_fm_tt < 0 || (xn_fm_tt && (T > 16 * xn_fm_tt || N % 32))) return UMB_EINVAL;
+  const size_t sm = 64 + (size_t)N * 2;
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((rmsnorm_kernel<P>), dim3(rows), dim3(256), 0, st, (u16*)out, (const u16*)x, (const u16*)w, eps, H);
+    hipLaunchKernelGGL((reduce_residual_norm_kernel<P>), dim3(T), dim3(1024), sm, st, (const float*)partial, S, T, N,
+                       (const u16*)residual, (u16*)h_out, (u16*)xn_out, (const u16*)w, eps, xn_fm_tt);
   })
   UMB_LAUNCH_CHECK();
   return UMB_OK;
@@ -378,14 +399,7 @@ extern "C" int umb_rmsnorm(void* out, const void* x, const void* w, float eps, i
 
 extern "C" int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
                                         void* xn_out, const void* w, float eps, int dtype, hipStream_t st) {
-  if (N % 4 || T < 1) return UMB_EINVAL;
-  const size_t sm = 64 + (size_t)N * 2;
-  DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((reduce_residual_norm_kernel<P>), dim3(T), dim3(1024), sm, st, (const float*)partial, S, T, N,
-                       (const u16*)residual, (u16*)h_out, (u16*)xn_out, (const u16*)w, eps);
-  })
-  UMB_LAUNCH_CHECK();
-  return UMB_OK;
+  return umb_reduce_residual_norm_fm(partial, S, T, N, residual, h_out, xn_out, w, eps, 0, dtype, st);
 }
 
 extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, hipStream_t st) {

@@ -38,10 +38,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-// element offset of (token t, feature f) in an FM-layout activation with TT token tiles
-__host__ __device__ __forceinline__ long fm_off(int t, int f, int TT) {
-  return ((((long)(f >> 5) * TT + (t >> 4)) * 64 + ((f >> 3) & 3) * 16 + (t & 15)) << 3) + (f & 7);
-}
+// fm_off(t, f, TT): element offset of (token t, feature f) in an FM-layout activation -- csrc/common.h
 
 enum { LL_LOGITS = 0, LL_SILU = 2, LL_QKV = 3, LL_RESID = 4 };
 

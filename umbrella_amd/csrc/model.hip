@@ -46,13 +46,14 @@ static inline int lin(const UmbLinear& l, const void* x, int ldx, void* out, int
 }
 
 // embedding (stage 0) / index resolution + hw = h * norm1_w and the per-64-column sums of squares of h
-static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st) {
+static int prologue(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, hipStream_t st,
+                    int fm_tt = 0) {
   if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
   if (ws->fused != 1) {
     CK(umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
                       s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
                       nullptr, nullptr, nullptr, 0, m->dtype, st));
-    return umb_rmsnorm(ws->xn, ws->h, first_norm, m->eps, s->T, m->H, m->dtype, st);
+    return umb_rmsnorm_fm(ws->xn, ws->h, first_norm, m->eps, s->T, m->H, fm_tt, m->dtype, st);
   }
   return umb_embed_prep(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
                         s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
@@ -81,41 +82,62 @@ static int tp_allreduce(const UmbTP* tp, float* partial, int* S, long TN, hipStr
   return tp->allreduce(tp->ctx, partial, (int64_t)TN, st) ? UMB_EHIP : UMB_OK;
 }
 
+// Round 4: forwards of <= 64 rows keep the split schedule's 16-bit activations (normed residual, attention output, SiLU output)
+// in FM order -- one MFMA B fragment = one contiguous KiB -- like the low-latency schedule's buffers: the skinny GEMMs stage them
+// with coalesced loads instead of 16 rows x 64 B per instruction (70B layer at 13 rows: qkv 12.7 -> 12.4, o 10.5 -> 10.1, gate/up
+// 44.6 -> 43.7, down 24.3 -> 23.5 us; 8B-AWQ at 32 rows: qkv 9.2 -> 8.1, gate/up 23.1 -> 21.9; profiles/r04_x_fm_probe.txt).  Same
+// values through the same MFMAs: the bits do not change.  Returns the token-tile count (0: row-major).  UMB_SPLIT_FM=0: A/B.
+static inline int split_fm_tt(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbTP* tp) {
+  static const bool off = getenv("UMB_SPLIT_FM") != nullptr && getenv("UMB_SPLIT_FM")[0] == '0';
+  // from 16 rows: whole forwards, FM vs row-major -- 8B-AWQ 16 / 32 rows 2.006 -> 1.969 / 2.475 -> 2.414 ms, 8B dense 31 rows 3.808 -> 3.684,
+  // 70B-AWQ at 13 rows 2.088 -> 2.085 (a 13-row tile is 19 % padding; the headline iteration measured 0.05 ms slower): stays row-major
+  if (off || ws->fused != 0 || tp_on(tp) || s->T > 64 || s->T < 16) return 0;
+  const int tt = umb_ll_token_tiles(s->T);
+  if (tt < 1 || ws->Tmax < 16 * tt || m->H % 32 || m->I % 32 || (m->Hq * m->D) % 32) return 0;
+  return tt;
+}
+
 // Schedule 0 (default): one decoder layer = 8 launches; split-K partials are reduced at kernel boundaries by
 // small epilogue kernels.  Measured faster on MI355X than schedule 1: an in-kernel cross-workgroup hand-off costs
 // as much as a kernel boundary on the 8-XCD part (profiles/README.md), and it serialises a tail onto every GEMM.
+// fm: token tiles of the FM-ordered activations (split_fm_tt; 0 = row-major); more: another layer of THIS forward follows, i.e.
+// the normed residual this layer leaves is a GEMM operand (FM) and not the lm_head's / the next pipeline stage's input (row-major)
 static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
-                       const void* next_norm, hipStream_t st, const UmbTP* tp = nullptr) {
+                       const void* next_norm, hipStream_t st, const UmbTP* tp = nullptr, int fm = 0, bool more = false) {
   const int T = s->T, dt = m->dtype;
   const size_t esz = 2;
   char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
   char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
-  CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, nullptr));
+  UmbGemmFused fxm = {}, fgu = {};
+  fxm.pad1 = 1;                                             // x in FM order
+  fgu.pad1 = 3;                                             // x and the SiLU output in FM order
+  const UmbGemmFused* xf = fm ? &fxm : nullptr;
+  CK(lin(ly.qkv, ws->xn, m->H, ws->partial, T, dt, st, 0, xf));
   CK(umb_reduce_qkv_rope(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
                          m->rope_sin, ws->q, kc, vt, /*paired=*/1, ly.qkv_bias, dt, st));
-  CK(umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
-                   s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
-                   ws->attn_counters, dt, st));
-  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, nullptr, true));
+  CK(umb_tree_attn2(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                    ws->attn_counters, fm, dt, st));
+  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, xf, true));
   int So = eff_s(ly.o, T, true);
   if (tp_peer(tp, (long)T * m->H)) {
     CK(umb_tp_publish(tp->peer, ws->partial, So, (int64_t)T * m->H, st));
     CK(umb_tp_reduce_residual_norm(tp->peer, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
   } else {
     CK(tp_allreduce(tp, ws->partial, &So, (long)T * m->H, st));
-    CK(umb_reduce_residual_norm(ws->partial, So, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, dt, st));
+    CK(umb_reduce_residual_norm_fm(ws->partial, So, T, m->H, ws->h, ws->h, ws->xn, ly.norm2, m->eps, fm, dt, st));
   }
   if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
-  CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, nullptr));
-  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, nullptr, true));
+  CK(lin(ly.gu, ws->xn, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, fm ? &fgu : nullptr));
+  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, xf, true));
   int Sd = eff_s(ly.down, T, true);
   if (tp_peer(tp, (long)T * m->H)) {
     CK(umb_tp_publish(tp->peer, ws->partial, Sd, (int64_t)T * m->H, st));
     CK(umb_tp_reduce_residual_norm(tp->peer, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt, st));
   } else {
     CK(tp_allreduce(tp, ws->partial, &Sd, (long)T * m->H, st));
-    CK(umb_reduce_residual_norm(ws->partial, Sd, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps, dt,
-                                st));
+    CK(umb_reduce_residual_norm_fm(ws->partial, Sd, T, m->H, ws->h, ws->h, next_norm ? ws->xn : nullptr, next_norm, m->eps,
+                                   more ? fm : 0, dt, st));
   }
   return UMB_OK;
 }
@@ -334,8 +356,8 @@ static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
 }
 
 static int layer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
-                 const void* next_norm, hipStream_t st) {
-  return ws->fused == 1 ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st);
+                 const void* next_norm, hipStream_t st, int fm = 0, bool more = false) {
+  return ws->fused == 1 ? layer_fused(m, ws, s, ly, l, next_norm, st) : layer_split(m, ws, s, ly, l, next_norm, st, nullptr, fm, more);
 }
 
 static int head(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, hipStream_t st) {
@@ -377,11 +399,12 @@ static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbSte
     return UMB_OK;
   }
   const bool ll = use_ll(ws, s);
+  const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
   int sg = 4;
-  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st));
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
   for (int l = lb; l < le; ++l) {
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(ll ? layer_ll(m, ws, s, m->layers[l], l, nn, &sg, st) : layer(m, ws, s, m->layers[l], l, nn, st));
+    CK(ll ? layer_ll(m, ws, s, m->layers[l], l, nn, &sg, st) : layer(m, ws, s, m->layers[l], l, nn, st, fm, l + 1 < le));
   }
   if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
@@ -454,8 +477,9 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
   if (pf) for (int i = 0; i < UMB_MAX_SLABS; ++i) pf[i] = -1;
 
   const bool ll = use_ll(ws, s);
+  const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
   int sg = 4;
-  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st));
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
   for (int l = lb; l < le; ++l) {
     UmbLayer cur = m->layers[l];
     int buf = -1;
@@ -465,7 +489,7 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       cur = rebase(m->layers[l], off->dev_slab[buf]);
     }
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(ll ? layer_ll(m, ws, s, cur, l, nn, &sg, st) : layer(m, ws, s, cur, l, nn, st));
+    CK(ll ? layer_ll(m, ws, s, cur, l, nn, &sg, st) : layer(m, ws, s, cur, l, nn, st, fm, l + 1 < le));
     if (buf >= 0) {
       ++used;
       if (hipEventRecord((hipEvent_t)off->ev_free[buf], st) != hipSuccess) return UMB_EHIP;
