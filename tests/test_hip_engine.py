@@ -206,7 +206,7 @@ def test_dynamic_reference_config_tree_shapes(dev, width, num_beams, depth, awq)
 
 @pytest.mark.parametrize("kind", ["static", "dynamic"])
 def test_long_context_crosses_the_attention_span_switch(dev, kind):
-    """A 740-token prompt and 60+ new tokens: the context passes the span switch (768 keys) inside the request, where the narrow tree-attention
+    """A 1000-token prompt and 60+ new tokens: the context passes the span switch (1024 keys) inside the request, where the narrow tree-attention
     launches (draft levels, static verify) switch from one span to 512-key spans merged by the last-arriving block -- inside
     the captured iteration graph, whose geometry must stay valid across the switch.  Every token is an arg-max of the fp32
     oracle and graph == eager."""
@@ -214,7 +214,7 @@ def test_long_context_crosses_the_attention_span_switch(dev, kind):
     dtype = torch.float16
     vocab = G["target_cfg"]["vocab_size"]
     g = torch.Generator().manual_seed(77)
-    prompt = torch.randint(6, vocab, (740,), generator=g).tolist()
+    prompt = torch.randint(6, vocab, (1000,), generator=g).tolist()
     outs = []
     for graph in (True, False):
         if kind == "static":
@@ -226,7 +226,7 @@ def test_long_context_crosses_the_attention_span_switch(dev, kind):
         outs.append(out["generated_tokens"])
         del eng
     assert outs[0] == outs[1]
-    assert len(outs[0]) >= 60                        # 740 + 60 > 768: both regimes ran
+    assert len(outs[0]) >= 60                        # 1000 + 60 > 1024: both regimes ran
     check_greedy(G, sd, prompt, outs[0], dtype, mask_first_eos=(3, 5) if kind == "dynamic" else None)
 
 

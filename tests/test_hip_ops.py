@@ -212,7 +212,7 @@ def _tree_mask(T, rs):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Hq,Hkv,D", [(4, 2, 64), (8, 1, 128), (32, 8, 64), (4, 4, 32)])
 @pytest.mark.parametrize("T,prefix", [(1, 0), (1, 300), (13, 5), (13, 777), (31, 64), (70, 129), (13, 2500), (5, 4200),
-                                      (13, 755), (13, 756), (13, 1012), (31, 1500)])     # narrow launches: one span up to 768 keys, then 512-key spans
+                                      (13, 1011), (13, 1012), (31, 1500)])     # narrow launches: one span up to 1024 keys, then 512-key spans
 @pytest.mark.parametrize("path", ["single", "split", "spans"])
 def test_tree_attention(dev, dtype, Hq, Hkv, D, T, prefix, path):
     """Tree-masked and causal attention vs the oracle through the three kernel paths: one launch, one 2048-key span

@@ -540,9 +540,10 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
   if (counters && Hkv * nqt < 256) {
     KBK = kbk_env >= 256 && kbk_env % 256 == 0 ? kbk_env : 512;
     while ((Lmax + KBK - 1) / KBK > max_splits && KBK < 2048) KBK *= 2;
-    // one span up to 768 keys: at 512-640 keys two spans measured +2 us per launch, at 1.6 k keys four spans -5.8 us; the
-    // headline engine at 600 / 800 / 1000-token prompts: 13.09 / 13.11 / 13.17 ms (512), 12.89 / 13.07 / 13.17 (768), 12.91 / 13.17 / 13.20 (1024)
-    single_max = one_env > 0 ? one_env : 768;
+    // one span up to 1024 keys.  Row-major cache (first A/B): 768 -- at 512-640 keys two spans +2 us per launch, at 1.6 k keys four spans
+    // -5.8 us.  On the fragment-ordered cache a round of the walk is cheaper and the merge is not: T = 13 at 760 / 1000 keys 9.8 / 10.1 us
+    // (768) vs 8.2 / 9.6 (1024), equal from 1200 keys; the headline engine at 700 / 900-token prompts 12.67 / 12.79 -> 12.56 / 12.74 ms
+    single_max = one_env > 0 ? one_env : 1024;
     if (single_max < KBK) single_max = KBK;
   }
   const int spans = (Lmax + KBK - 1) / KBK;
