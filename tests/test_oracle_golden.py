@@ -54,6 +54,37 @@ def test_kv_gather_matches_reference():
         assert c.kv_offset == int(OPS["gather_offset"])
 
 
+def test_fragment_ordered_cache_speaks_the_reference_gather():
+    """The product's KV cache stores each (layer, kv head) slab in MFMA fragment order (umbrella_amd/attn/cache.py); its
+    host-side views must still behave like the reference's cache: the recorded `gather_kv_incremental` vector of the reference
+    (KV_Cache, cache.py:41-49; [L, Lmax, Hkv, D]) through set_rows -> gather -> k_rows / v_rows, the converters round trip, and the
+    offset formulas are permutations of a slab.  CPU only (torch index arithmetic; the device kernels share the formulas)."""
+    from umbrella_amd.attn.cache import (TreeKVCache, VT_PAD, k_from_frag, k_offsets, k_to_frag, vt_from_frag, vt_offsets,
+                                         vt_to_frag)
+    kb, vb = T(OPS["gather_k_before"]), T(OPS["gather_v_before"])            # [1, Lmax 32, Hkv 2, D 64]
+    L, Lmax, Hkv, D = kb.shape
+    c = TreeKVCache(L, Hkv, D, Lmax, "cpu", torch.float32)
+    allpos = torch.arange(Lmax)
+    c.set_rows(allpos, kb.permute(0, 2, 1, 3), vb.permute(0, 2, 1, 3))
+    c.gather_kv_incremental(torch.tensor([9, 11, 14]), 9)
+    assert c.kv_offset == int(OPS["gather_offset"])
+    n = c.kv_offset                       # the reference zeroes the tail (cache.py:46-47); this cache leaves it, it is never visible
+    assert torch.equal(c.k_rows(allpos[:n]).permute(0, 2, 1, 3), T(OPS["gather_k_after"])[:, :n])
+    assert torch.equal(c.v_rows(allpos[:n]).permute(0, 2, 1, 3), T(OPS["gather_v_after"])[:, :n])
+    # storage <-> semantic converters
+    ks = k_from_frag(c.k)
+    assert torch.equal(ks[:, :, :n], T(OPS["gather_k_after"]).permute(0, 2, 1, 3)[:, :, :n]) and torch.equal(k_to_frag(ks), c.k)
+    vs = vt_from_frag(c.vt)
+    assert torch.equal(vs[..., :n], T(OPS["gather_v_after"]).permute(0, 2, 3, 1)[..., :n]) and torch.equal(vt_to_frag(vs), c.vt)
+    assert float(c.vt.reshape(L, Hkv, -1)[..., Lmax * D:].abs().max()) == 0.0 and c.vt.shape[-1] == Lmax + VT_PAD
+    for Dh, Lm in ((32, 64), (64, 96), (128, 160)):
+        ko, vo = k_offsets(torch.arange(Lm), Dh).reshape(-1), vt_offsets(torch.arange(Lm), Dh).reshape(-1)
+        assert torch.equal(ko.sort().values, torch.arange(Lm * Dh)) and torch.equal(vo.sort().values, torch.arange(Lm * Dh))
+        # one K fragment = 16 keys x 32 features in 512 consecutive elements; one V^T fragment = 16 features x 32 keys
+        frag = (ko.reshape(Lm, Dh)[:32, :32] // 512).unique()
+        assert frag.numel() == 2 and (vo.reshape(Dh, Lm)[:16, :32] // 512).unique().numel() == 1
+
+
 def test_logit_helpers_match_reference():
     lg, ids = T(OPS["rp_logits"]), T(OPS["rp_ids"])
     assert torch.equal(ops.repetition_penalty(ids, lg, 1.05), T(OPS["rp_out"]))
