@@ -264,8 +264,9 @@ def roofline_block(eng):
     import hashlib
     with open(os.path.join(ROOT, "umbrella_amd", "csrc", "gemm.hip"), "rb") as f:
         src_hash = hashlib.sha256(f.read()).hexdigest()[:16]
-    for pmc_name in ("r03_pmc_gemm70b_traffic.json", "r02_pmc_gemm70b_traffic.json"):
-        pmc = os.path.join(ROOT, "profiles", pmc_name)
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm70b_traffic.json")), reverse=True):   # newest round first
+        pmc_name = os.path.basename(pmc)
         if m.config.awq and dom["N"] == 57344 and dom["K"] == 8192 and os.path.exists(pmc):
             with open(pmc) as f:
                 rec = json.load(f)
