@@ -526,13 +526,25 @@ def secondary_configs(device, seed=0):
             eng = AutoEngine.from_config(device, engine="dynamic", model=T70, draft_model=D1B, dtype=torch.float16, width=16,
                                          num_beams=24, depth=16, max_length=4096, offload=True, num_cache_layers=ncl, seed=seed)
             eng.initialize()
-            ms, acc = _timed_steps(eng, prompt, 1, 3)
+            # per-step times after two warm steps, median of three (all three are reported)
+            assert eng._prefill(prompt)
+            for _ in range(2):
+                eng.step()
+            torch.cuda.synchronize()
+            times, start = [], eng.num_nodes
+            for _ in range(3):
+                t0 = time.time()
+                eng.step()
+                torch.cuda.synchronize()
+                times.append((time.time() - t0) * 1e3)
+            ms, acc = sorted(times)[1], (eng.num_nodes - start) / 3
             m = eng.target_model
             streamed = sum(1 for h in m.host_slabs if h is not None) * m.slab_bytes
             return {"config": f"C3: 70B-AWQ layers streamed from pinned host DRAM, num_cache_layers {ncl}, 1B draft, dynamic "
                               "w16/b24/d16 (T=257)", "ms_per_step": round(ms, 1), "accept_len_raw_draft": round(acc, 2),
                     "streamed_GB_per_verify": round(streamed / 1e9, 2), "bound": "host link (PCIe Gen5 x16, 63 GB/s spec)",
-                    "achieved_GBs": round(streamed / ms / 1e6, 1), "frac": round(streamed / ms / 1e6 / 63.0, 4)}
+                    "achieved_GBs": round(streamed / ms / 1e6, 1), "frac": round(streamed / ms / 1e6 / 63.0, 4),
+                    "step_ms": [round(t, 1) for t in times]}
         return run
 
     guarded("c2", c2)
@@ -541,8 +553,22 @@ def secondary_configs(device, seed=0):
     guarded("prefill_70b", prefill)
     shared.clear()
     torch.cuda.empty_cache()
+    def fresh_host():
+        # Every offload configuration pins fresh host memory, as a process running it alone does (torch caches pinned blocks).  The
+        # 40-resident-layer figure still varies with the process's history on the host side -- 330 ms per step stand-alone
+        # (scripts/bench_configs.py), 332 / 357 / 377 inside this script on the same build depending on the headline's length and
+        # the box, each steady over its steps (`step_ms`) -- while the all-streamed one does not (647-656): pinned-page placement
+        # relative to the GPU's socket is the suspect; the link, not a kernel, is what moves.
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if hasattr(torch._C, "_host_emptyCache"):
+            torch._C._host_emptyCache()
+    fresh_host()
     guarded("c3_offload_ncl0", c3_offload(0))
+    fresh_host()
     guarded("c3_offload_ncl40", c3_offload(40))
+    fresh_host()
     return out
 
 
