@@ -130,6 +130,35 @@ int umb_gemv(void* out, const void* x, const void* w_rows, int T, int N, int K, 
  * partner pairs over rope_heads heads of size D), 16-bit elements, K % 8 == 0 */
 int umb_repack_rows(void* out, const void* w, int N, int K, int mode, int D, int rope_heads, umb_stream_t stream);
 
+/* ------------------------------------------------------------------ persistent chain (csrc/chain.hip; round 5)
+ * The draft model's <= 4-row layer as TWO launches: tree attention + ONE persistent launch that runs
+ *   o-projection + residual -> gate/up + SiLU -> down-projection + residual -> the NEXT layer's q/k/v + RoPE + KV append
+ * (umbrella/models/llama.py:461-533, LlamaCudagraph.layer_compute / graph_inference: the reference replays ~25 launches per
+ * layer from one CUDA graph; umb_gemv runs 5).  One workgroup per CU: a loader wave streams the CU's rows of every op's
+ * w_rows HBM -> LDS (LDS-DMA, 16 KiB slots, running ahead of the dependency edges), three consumer waves compute with
+ * v_dot2; the [T][N] edges travel as 8-byte {tag, value} granules through `xchg`.  Bit-identical to the umb_gemv chain.
+ * front: o / gate-up / down present (reads attn, h; writes h, hw = h * next_norm, ssq[t][0 .. 256)); tail: q/k/v present
+ * (writes q_out and the K / V^T caches at slot[t]).  front = 0, tail = 1 is the forward's first q/k/v: x = hw, 1/rms from
+ * ssq[t][0 .. ssq_groups_in).  xchg: umb_chain_xchg_bytes(Tmax, H, I) device bytes, zeroed once, then the epoch word at
+ * its end set to 1 (umb_chain_xchg_init); a launch that gives up on a hand-off (every spin is bounded: 20 ms, or
+ * UMB_CHAIN_TIMEOUT_MS) ORs 0xDEADxxxx into the status word (umb_chain_status).  Needs every workgroup resident: one
+ * process per device.  umb_chain_ok: 1 where the shape is covered (H 2048, I 8192, T <= 4, no q/k/v bias, 256 CUs;
+ * 0 with UMB_NO_CHAIN=1). */
+typedef struct UmbChain {
+  const void* w_o; const void* w_gu; const void* w_down; const void* w_qkv;   /* umb_repack_rows copies */
+  const void* attn; void* h; void* hw; float* ssq;
+  const void* norm2; const void* next_norm;
+  const int32_t* pos; const int32_t* slot; const void* cosT; const void* sinT; void* q_out; void* k_cache; void* vt_cache;
+  void* xchg;
+  int32_t T, Tmax, front, tail, H, I, NQKV, ssq_stride, ssq_groups_in, Hq, Hkv, D, Lmax;
+  float eps;
+} UmbChain;
+int umb_chain_ok(int T, int H, int I, int NQKV, int D, int has_bias);
+size_t umb_chain_xchg_bytes(int Tmax, int H, int I);
+int umb_chain_xchg_init(void* xchg, int Tmax, int H, int I, umb_stream_t stream);
+int umb_chain_status(const void* xchg, int Tmax, int H, int I, uint32_t* status_out, umb_stream_t stream);
+int umb_draft_chain(const UmbChain* c, int dtype, umb_stream_t stream);
+
 /* (R n-tiles per wave, WN row groups x WK K-slices = NW waves per block) for a [N][K] linear: shape-only, so a
  * token's result never depends on its batch mates; epi 4 writes N / 16 / R sums of squares per token. */
 void umb_ll_plan(int N, int K, int awq, int* R_out, int* WN_out, int* WK_out, int* NW_out);
@@ -325,6 +354,8 @@ typedef struct UmbWorkspace {
   int32_t fused, pad_;              /* layer schedule: 0 = 8 launches (split-K reduced at kernel boundaries), 1 = 5 launches
                                        (in-kernel last-arriver reduces; slower), 2 = low-latency 5 launches (whole-K
                                        workgroups, FM activations; T <= 64 only, wider forwards use schedule 0) */
+  void* chain_xchg;                 /* NULL, or umb_chain_xchg_bytes(Tmax, H, I) bytes (umb_chain_xchg_init): forwards of
+                                       <= 4 rows of a GEMV-role model run the persistent chain (csrc/chain.hip) */
 } UmbWorkspace;
 
 typedef struct UmbStep {

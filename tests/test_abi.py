@@ -36,7 +36,8 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(_lib.UmbLinear) == 56
     assert C.sizeof(_lib.UmbLayer) == 4 * 56 + 24
     assert C.sizeof(_lib.UmbModel) == 10 * 4 + 8 + 8 + 56 + 6 * 8
-    assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24
+    assert C.sizeof(_lib.UmbWorkspace) == 16 * 8 + 24 + 8
+    assert C.sizeof(_lib.UmbChain) == 18 * 8 + 14 * 4
     assert C.sizeof(_lib.UmbGemmFused) == 144
     assert C.sizeof(_lib.UmbGemmLL) == 152
     assert C.sizeof(_lib.UmbStep) == 8 + 8 * 8 + 6 * 4

@@ -50,7 +50,18 @@ class UmbWorkspace(C.Structure):
                 ("pos", C.c_void_p), ("slot", C.c_void_p), ("prefix", C.c_void_p), ("logits", C.c_void_p),
                 ("hw", C.c_void_p), ("ssq", C.c_void_p), ("counters", C.c_void_p), ("attn_counters", C.c_void_p),
                 ("Tmax", C.c_int32), ("attn_chunk", C.c_int32), ("attn_splits", C.c_int32), ("ssq_stride", C.c_int32),
-                ("fused", C.c_int32), ("pad_", C.c_int32)]
+                ("fused", C.c_int32), ("pad_", C.c_int32), ("chain_xchg", C.c_void_p)]
+
+
+class UmbChain(C.Structure):
+    _fields_ = [("w_o", C.c_void_p), ("w_gu", C.c_void_p), ("w_down", C.c_void_p), ("w_qkv", C.c_void_p),
+                ("attn", C.c_void_p), ("h", C.c_void_p), ("hw", C.c_void_p), ("ssq", C.c_void_p),
+                ("norm2", C.c_void_p), ("next_norm", C.c_void_p), ("pos", C.c_void_p), ("slot", C.c_void_p),
+                ("cosT", C.c_void_p), ("sinT", C.c_void_p), ("q_out", C.c_void_p), ("k_cache", C.c_void_p),
+                ("vt_cache", C.c_void_p), ("xchg", C.c_void_p),
+                ("T", C.c_int32), ("Tmax", C.c_int32), ("front", C.c_int32), ("tail", C.c_int32), ("H", C.c_int32),
+                ("I", C.c_int32), ("NQKV", C.c_int32), ("ssq_stride", C.c_int32), ("ssq_groups_in", C.c_int32),
+                ("Hq", C.c_int32), ("Hkv", C.c_int32), ("D", C.c_int32), ("Lmax", C.c_int32), ("eps", C.c_float)]
 
 
 class UmbGemmFused(C.Structure):
@@ -120,6 +131,11 @@ SIGNATURES = {
     "umb_gemv_ok": [_I, _I, _I, _I],
     "umb_gemv_groups": [_I, _I, _I],
     "umb_repack_rows": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "umb_chain_ok": [_I, _I, _I, _I, _I, _I],
+    "umb_chain_xchg_bytes": [_I, _I, _I],
+    "umb_chain_xchg_init": [_P, _I, _I, _I, _P],
+    "umb_chain_status": [_P, _I, _I, _I, C.POINTER(C.c_uint32), _P],
+    "umb_draft_chain": [C.POINTER(UmbChain), _I, _P],
     "umb_ll_plan": [_I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "umb_ll_token_tiles": [_I],
     "umb_to_fm": [_P, _P, _I, _I, _I, _P],
@@ -167,6 +183,7 @@ SIGNATURES = {
 }
 _VOID = {"umb_gemm_plan", "umb_gemm_plan2", "umb_ll_plan"}
 _STR = {"umb_version"}
+_SIZE = {"umb_chain_xchg_bytes"}
 
 _lib = None
 
@@ -184,7 +201,7 @@ def load() -> C.CDLL:
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the ABI is incomplete
         fn.argtypes = args
-        fn.restype = None if name in _VOID else (C.c_char_p if name in _STR else C.c_int)
+        fn.restype = None if name in _VOID else (C.c_char_p if name in _STR else (C.c_size_t if name in _SIZE else C.c_int))
     _lib = lib
     return lib
 

@@ -92,6 +92,14 @@ template <typename P> __device__ __forceinline__ float mul_rnd(float x, float y)
   asm volatile("" : "+v"(p));
   return p;
 }
+// round(x * y) for fp32 operands, as TWO roundings (fp32 product, then the model dtype) whatever the surrounding code: left
+// alone, hipcc picks v_fma_mixlo_f16 (one rounding) in some kernels and v_mul_f32 + v_cvt (two) in others -- the GEMV
+// launches and the persistent chain (chain.hip) must agree bit for bit, and they differed at ~1 output in 8000.
+template <typename P> __device__ __forceinline__ float rnd_prod(float x, float y) {
+  float p = x * y;
+  asm volatile("" : "+v"(p));
+  return rnd<P>(p);
+}
 template <typename P> __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)P::from_f(lo) | ((unsigned)P::from_f(hi) << 16);
 }

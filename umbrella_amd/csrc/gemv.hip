@@ -204,14 +204,14 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
         const float h0 = rnd<P>(rnd<P>(val[r]) + P::to_f(er[B].hv[r]));
         a.h[off] = P::from_f(h0);
         if (a.norm_w) a.hw[off] = P::from_f(h0 * P::to_f(er[B].nw[r]));
-        sq_acc += h0 * h0;
+        sq_acc = __builtin_fmaf(h0, h0, sq_acc);      // pinned (chain.hip reproduces this order bit for bit)
       }
     } else if constexpr (EPI == GV_SILU) {
       // rows (2m, 2m+1) = (gate_m, up_m); every step rounded to the model dtype as eager torch does (llama.py:107-110)
       u16* act = reinterpret_cast<u16*>(a.out);
 #pragma unroll
       for (int r = 0; r < RW; r += 2) {
-        const float g0 = rnd<P>(val[r] * iv), u0 = rnd<P>(val[r + 1] * iv);
+        const float g0 = rnd_prod<P>(val[r], iv), u0 = rnd_prod<P>(val[r + 1], iv);
         act[(long)t * (N / 2) + ((n0 + r) >> 1)] = P::from_f(rnd<P>(g0 / (1.f + __expf(-g0))) * u0);
       }
     } else {
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(512) void gv_kernel(const u32x4* __restrict__ w, co
         const int n = n0 + r;
         const int head = n / D, dp = n % D, m = dp >> 1;
         float va = val[r] * iv, vb = val[r + 1] * iv;
+        asm volatile("" : "+v"(va), "+v"(vb));       // fp32 products of their own (common.h: rnd_prod)
         if (a.bias) { va += P::to_f(er[B].bs[r]); vb += P::to_f(er[B].bs[r + 1]); }
         const float a0 = rnd<P>(va), b0 = rnd<P>(vb);
         if (head < a.Hq + a.Hkv) {

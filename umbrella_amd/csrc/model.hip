@@ -345,6 +345,45 @@ static int layer_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s,
   *groups = umb_gemv_groups(T, ly.down.N, ly.down.K);
   return UMB_OK;
 }
+// ---- persistent chain (chain.hip): the GEMV schedule's layer as tree attention + ONE launch (o, gate/up, down, next q/k/v)
+static inline bool use_chain(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s) {
+  if (!ws->chain_xchg || ws->ssq_stride < 256) return false;
+  for (int l = s->layer_begin; l < s->layer_end; ++l)
+    if (m->layers[l].qkv_bias) return false;
+  const UmbLayer& ly = m->layers[s->layer_begin];
+  if (ly.o.N != m->H || ly.down.N != m->H || ly.gu.N != 2 * m->I) return false;
+  return umb_chain_ok(s->T, m->H, m->I, ly.qkv.N, m->D, 0) != 0;
+}
+// lf: layer whose o / gate-up / down run (-1: none); lt: layer whose q/k/v runs (-1: none)
+static int chain_launch(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int lf, int lt, const void* next_norm,
+                        int groups_in, hipStream_t st) {
+  UmbChain c = {};
+  if (lf >= 0) {
+    const UmbLayer& ly = m->layers[lf];
+    c.front = 1; c.w_o = ly.o.w_rows; c.w_gu = ly.gu.w_rows; c.w_down = ly.down.w_rows; c.norm2 = ly.norm2;
+    c.attn = ws->attn;
+  }
+  if (lt >= 0) {
+    const UmbLayer& ly = m->layers[lt];
+    c.tail = 1; c.w_qkv = ly.qkv.w_rows;
+    c.k_cache = (char*)m->k_cache + (size_t)lt * m->Hkv * m->Lmax * m->D * 2;
+    c.vt_cache = (char*)m->vt_cache + (size_t)lt * m->Hkv * VT_LD(m->Lmax) * m->D * 2;
+    c.pos = ws->pos; c.slot = ws->slot; c.cosT = m->rope_cos; c.sinT = m->rope_sin; c.q_out = ws->q;
+  }
+  c.NQKV = m->layers[lt >= 0 ? lt : lf].qkv.N;
+  c.h = ws->h; c.hw = ws->hw; c.ssq = ws->ssq; c.next_norm = next_norm; c.xchg = ws->chain_xchg;
+  c.T = s->T; c.Tmax = 4;                    /* the exchange is sized for <= 4 rows (umb_chain_xchg_bytes(4, H, I)) */
+   c.H = m->H; c.I = m->I; c.ssq_stride = ws->ssq_stride; c.ssq_groups_in = groups_in;
+  c.Hq = m->Hq; c.Hkv = m->Hkv; c.D = m->D; c.Lmax = m->Lmax; c.eps = m->eps;
+  return umb_draft_chain(&c, m->dtype, st);
+}
+static int attn_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int l, hipStream_t st) {
+  char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * 2;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * 2;
+  return umb_tree_attn(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                       s->n_mask_keys, s->T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                       ws->attn_counters, m->dtype, st);
+}
 static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int groups, hipStream_t st) {
   if (s->head_from >= s->T) return UMB_OK;
   const int rows = s->T - s->head_from;
@@ -391,6 +430,18 @@ static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbSte
   if (use_gv(m, ws, s)) {
     int groups = 0;
     CK(prologue_gv(m, ws, s, m->layers[lb].norm1, &groups, st));
+    if (use_chain(m, ws, s)) {
+      // 2 launches per layer: the first q/k/v alone, then per layer tree attention + the chain into the next q/k/v
+      CK(chain_launch(m, ws, s, -1, lb, nullptr, groups, st));
+      for (int l = lb; l < le; ++l) {
+        const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
+        CK(attn_gv(m, ws, s, l, st));
+        CK(chain_launch(m, ws, s, l, l + 1 < le ? l + 1 : -1, nn, 0, st));
+      }
+      groups = umb_gemv_groups(s->T, m->layers[lb].down.N, m->layers[lb].down.K);
+      if (le == m->L) CK(head_gv(m, ws, s, groups, st));
+      return UMB_OK;
+    }
     for (int l = lb; l < le; ++l) {
       const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
       CK(layer_gv(m, ws, s, m->layers[l], l, nn, &groups, st));

@@ -469,6 +469,41 @@ class Llama(LLMBase):
                 streamed = self.host_slabs[i] is not None
                 getattr(self._layer_structs[i], key).w_rows = rows.data_ptr() if (on and rows is not None and not streamed) else 0
         self.gemv = bool(on)
+        self._chain_setup()
+
+    def _chain_setup(self):
+        """Persistent chain (csrc/chain.hip): with the draft role on and a covered shape (umb_chain_ok: 1B-class dense
+        models, <= 3 rows, no q/k/v bias, a 256-CU device) the <= 3-row forwards run as tree attention + ONE persistent
+        launch per layer.  The launch needs every workgroup resident, i.e. this process alone on the device.
+        UMB_CHAIN=1 switches it on (default off while the five GEMV launches are the faster schedule: DESIGN.md 7b)."""
+        c = self.config
+        lib = _lib.load()
+        on = (getattr(self, "gemv", False) and os.environ.get("UMB_CHAIN", "0") != "0" and self._tp is None
+              and self._off is None and hasattr(self, "_ws")
+              and all(getattr(ln, "w_rows", None) is not None for lins in self.layers for ln in lins.values()))
+        has_bias = int(any(getattr(st, "qkv_bias", None) for st in self._layer_structs))
+        nqkv = c.q_dim + 2 * c.num_key_value_heads * c.head_dim
+        if on and lib.umb_chain_ok(1, c.hidden_size, c.intermediate_size, nqkv, c.head_dim, has_bias):
+            if getattr(self, "_chain_xchg", None) is None:
+                n = lib.umb_chain_xchg_bytes(4, c.hidden_size, c.intermediate_size)
+                self._chain_xchg = torch.zeros(n, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.umb_chain_xchg_init(self._chain_xchg.data_ptr(), 4, c.hidden_size, c.intermediate_size,
+                                                   _lib.stream_ptr()), "umb_chain_xchg_init")
+            self._ws.chain_xchg = self._chain_xchg.data_ptr()
+        elif hasattr(self, "_ws"):
+            self._ws.chain_xchg = 0
+        self.chain = bool(hasattr(self, "_ws") and self._ws.chain_xchg)
+
+    def chain_status(self) -> int:
+        """Sticky give-up word of the persistent chain's bounded hand-off spins (0: every launch so far completed its
+        hand-offs; 0xDEADxxxx: workgroup xxxx timed out -- the device was shared, results after that are invalid)."""
+        if getattr(self, "_chain_xchg", None) is None:
+            return 0
+        c = self.config
+        out = C.c_uint32(0)
+        _lib.check(_lib.load().umb_chain_status(self._chain_xchg.data_ptr(), 4, c.hidden_size, c.intermediate_size,
+                                                C.byref(out), _lib.stream_ptr()), "umb_chain_status")
+        return int(out.value)
 
     def reserve(self, tokens: int, logit_rows: int | None = None):
         """Size the activation workspace for forwards of up to `tokens` rows (`logit_rows` of which may go through the
@@ -518,6 +553,8 @@ class Llama(LLMBase):
         ws.counters, ws.attn_counters = self._counters.data_ptr(), self._attn_counters.data_ptr()
         ws.Tmax, ws.attn_chunk, ws.attn_splits, ws.ssq_stride = T, self.attn_chunk, self.attn_splits, self.ssq_stride
         ws.fused = 2 if (self.sched == "ll" and not self.fused) else int(self.fused)
+        if getattr(self, "chain", False):
+            self._chain_setup()
 
     @property
     def logits_buffer(self) -> torch.Tensor:
