@@ -16,6 +16,7 @@ dev = torch.device("cuda:0")
 trace = torch.zeros(64, 256, 4, 32, dtype=torch.int64, device=dev)
 os.environ["UMB_CHAIN_TRACE_PTR"] = hex(trace.data_ptr())
 os.environ["UMBRELLA_SYNTHETIC"] = "1"
+os.environ["UMB_CHAIN"] = "1"
 from umbrella_amd.models.config import KNOWN  # noqa: E402
 from umbrella_amd.models.llama import Llama  # noqa: E402
 
@@ -69,6 +70,10 @@ n_slots = 29
 for i in (1, 2, 3, 6, 7, 8, 12, 18, 19, 20, 26, 27, 28, 29):
     stat(tr[:, 0, i], f"slot {i - 1} issued" if i <= n_slots else "slot")
 stat(tr[:, 0, 30], "all landed")
+import numpy as np
+fn, ft = tr[:, 0, 31] >> 48, tr[:, 0, 31] & ((1 << 48) - 1)
+print(f"  ring-full episodes per loader: med {np.median(fn):.0f} max {fn.max()}; time spent in them: med "
+      f"{np.median(ft) / 100:.2f} us max {ft.max() / 100:.2f} us")
 labels = ["start", "o slots done", "h1 gathered", "gate/up operand built", "gate/up slots done", "act gathered",
           "down slots done", "h2 gathered", "q/k/v done (end)"]
 for w in (1, 2, 3):

@@ -25,6 +25,12 @@
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(3))) char lds_char;
+// every LDS word this kernel polls or publishes is addressed through an address_space(3) pointer: a generic pointer makes
+// hipcc emit FLAT loads / stores, which count in vmcnt as well -- the loader's flag polls then waited for its whole DMA
+// stream (s_waitcnt vmcnt(0) in front of every slot: 0.9 instead of 0.63 us per slot)
+typedef __attribute__((address_space(3))) volatile unsigned lds_vu;
+typedef __attribute__((address_space(3))) unsigned lds_u;
+typedef __attribute__((address_space(3))) volatile float lds_vf;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 typedef _Float16 ch_h2 __attribute__((ext_vector_type(2)));
@@ -75,8 +81,8 @@ template <int TT> __device__ __forceinline__ float ch_fold(const float (&v)[TT])
 
 enum { CH_SLOT = 16384, CH_MAXRING = 8 };
 // flag words (u32 index into the flag area)
-enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41, F_SQ = 48 /* float [8][4] */,
-       F_HV = 80 /* u32 [8][4] */, F_WORDS = 128 };
+enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41,
+       F_SQ = 48 /* float [8][4] */, F_HV = 80 /* u32 [8][4] */, F_WORDS = 128 };
 
 struct ChainArgs {
   const char* w_o; const char* w_gu; const char* w_down; const char* w_qkv;      // row-major packed-order rows
@@ -103,7 +109,7 @@ struct ChainArgs {
 __device__ __forceinline__ void ch_sleep() { __builtin_amdgcn_s_sleep(2); }
 
 // bounded wait on an LDS word (>= target); returns false after the deadline (status set by the caller)
-__device__ __forceinline__ bool lds_wait_ge(volatile unsigned* w, unsigned target, long long deadline, volatile unsigned* dead) {
+__device__ __forceinline__ bool lds_wait_ge(lds_vu* w, unsigned target, long long deadline, lds_vu* dead) {
   unsigned spins = 0;                                // every value that steers the loop is made wave-uniform (SGPR control flow)
   while (__builtin_amdgcn_readfirstlane(*w) < target) {
     ch_sleep();
@@ -126,14 +132,14 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cu = blockIdx.x;
-  volatile unsigned* fl = (volatile unsigned*)(smem + off_flags);
-  if (threadIdx.x < F_WORDS) ((unsigned*)(smem + off_flags))[threadIdx.x] = 0;
+  lds_vu* fl = (lds_vu*)((lds_char*)smem + off_flags);
+  if (threadIdx.x < F_WORDS) fl[threadIdx.x] = 0;
   __syncthreads();                                   // the only workgroup barrier of the launch
   const int T = a.T;
   int tr_n = 0; (void)tr_n;
   CH_STAMP();                                        // 0: wave start
   const long long deadline = (long long)wall_clock64() + (long long)timeout_ticks;
-  volatile unsigned* dead = fl + F_DEAD;
+  lds_vu* dead = fl + F_DEAD;
   // slots per CU of each op (rows per CU x bytes per row / 16 KiB); H = 2048, I = 8192 (umb_chain_ok)
   const int ncu = gridDim.x;
   const int s_o = a.front ? (a.H / ncu) * a.H * 2 / CH_SLOT : 0;
@@ -151,6 +157,9 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     const unsigned voff = (unsigned)lane * 16u;
     const bool lfront = (front_tail & 1) != 0, ltail = (front_tail & 2) != 0;
     int i = 0, p = 0;                                  // global slot index, ring position
+#ifdef UMB_CHAIN_TRACE
+    unsigned long long full_ticks = 0, full_n = 0;     // ring-full episodes of this loader
+#endif
     auto flag_landed = [&](int slot_i) {               // slot_i has landed: its ring position carries slot_i + 1
       if (lane == 0) fl[F_LANDED + slot_i % R] = (unsigned)slot_i + 1u;
     };
@@ -161,11 +170,18 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
         if (i >= R) {
           // ring full: nothing to overlap with, so drain what is in flight and publish it, then wait for the slot
           if (__builtin_amdgcn_readfirstlane(fl[F_FREED + p]) < (unsigned)(i - R + 1)) {
+#ifdef UMB_CHAIN_TRACE
+            const unsigned long long tf0 = wall_clock64();
+            ++full_n;
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (i >= 3) flag_landed(i - 3);
             if (i >= 2) flag_landed(i - 2);
             if (i >= 1) flag_landed(i - 1);
             if (!lds_wait_ge(fl + F_FREED + p, (unsigned)(i - R + 1), deadline, dead)) return;
+#ifdef UMB_CHAIN_TRACE
+            full_ticks += wall_clock64() - tf0;
+#endif
           }
         }
         const unsigned dst = ring0 + (unsigned)p * CH_SLOT;
@@ -201,6 +217,9 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (i >= 1) flag_landed(i - 1);
     CH_STAMP();                                        // loader: everything landed
+#ifdef UMB_CHAIN_TRACE
+    if (a.trace && lane == 0) a.trace[((size_t)cu * 4) * 32 + 31] = full_ticks | (full_n << 48);
+#endif
     return;
   }
 
@@ -277,26 +296,30 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   }
 
   // ---- helpers
-  auto wait_slot = [&](int gi) -> const char* {        // ring position of global slot gi, once it has landed
+  auto wait_slot = [&](int gi) -> const lds_char* {        // ring position of global slot gi, once it has landed
     const int p = gi % R;
     if (ok && !lds_wait_ge(fl + F_LANDED + p, (unsigned)gi + 1u, deadline, dead)) ok = false;
     asm volatile("" ::: "memory");
-    return smem + (size_t)p * CH_SLOT;
+    return (const lds_char*)smem + (size_t)p * CH_SLOT;
   };
   auto free_slot = [&](int gi) {                       // the slot's bytes are in registers
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) fl[F_FREED + gi % R] = (unsigned)gi + 1u;
   };
-  // four K = 2048 rows of one slot against the TT operand rows.  The 4 TT accumulators advance TOGETHER, one k pair at a
-  // time (a v_dot2c waits for its own previous result: one chain alone issues every ~9 cycles); each chain still adds its
-  // products in gv_kernel's order.  acc[r]: row t of the wave = token t's sum for weight row r
-  auto rows4 = [&](const char* sp, int gi, float (&acc)[4]) {
-    u32x4 wr[4][4];
+  // four K = 2048 rows of one slot: load4 pulls them into registers and frees the ring slot -- also AHEAD of a dependency
+  // edge (the operand of the op is not there yet, but registers are idle then and the loader gets its slot back: the ring
+  // grows by what the consumers hold); compute4 runs them against the TT operand rows.  The 4 TT accumulators advance
+  // TOGETHER, one k pair at a time (a v_dot2c waits for its own previous result: one chain alone issues every ~9 cycles);
+  // each chain still adds its products in gv_kernel's order.  acc[r]: row t of the wave = token t's sum for weight row r
+  auto load4 = [&](int gi, u32x4 (&wr)[4][4]) {
+    const lds_char* sp = wait_slot(gi);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) wr[r][kc] = *(const u32x4*)(sp + r * 4096 + kc * 1024 + lane * 16);
+      for (int kc = 0; kc < 4; ++kc) wr[r][kc] = *(const __attribute__((address_space(3))) u32x4*)(sp + r * 4096 + kc * 1024 + lane * 16);
     free_slot(gi);
+  };
+  auto compute4 = [&](const u32x4 (&wr)[4][4], float (&acc)[4]) {
     float part[4][TT];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -313,33 +336,62 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = ch_fold<TT>(part[r]);
   };
-  // sweep an edge's granules into LDS staging (flat u32 index == flat granule index), then meet the other consumers
-  auto gather = [&](gu64* g, int chunks, unsigned tag, unsigned* stage) {
-    for (int c = cw; c < chunks; c += 3) {
-      gu64* gp = g + (size_t)c * 1024 + lane;
-      unsigned val[16];
+  // sweep an edge's granules into LDS staging (flat u32 index == flat granule index), then meet the other consumers.
+  // NCH: this consumer's chunks (1024 granules each), ALL polled in one pass -- an edge completes with its slowest
+  // producer, whose granules sit in every chunk alike: chunk after chunk would put NCH passes behind that arrival, this one
+  // Before the full sweep, ONE 512-byte piece of the edge is polled (a different piece on every CU and consumer, so the
+  // pollers spread over the edge): re-reading a whole incomplete edge moves as many bytes per CU as the weight stream
+  // itself (three waves x 8 KiB per pass) and slowed the loaders by a third.  The piece is a hint -- its 64 granules come
+  // from 4 - 16 producers, the others finish around the same time -- the tags of the full sweep decide.
+  auto gather = [&](auto nch, gu64* g, int chunks, unsigned tag, lds_u* stage, auto&& idle) {
+    constexpr int NCH = decltype(nch)::value;
+    if (cw < chunks) {
+      gu64* hp = g + (size_t)cw * 1024 + (size_t)((cu + 5 * cw) & 15) * 64 + lane;
       unsigned spins = 0;
       for (;;) {
-        bool good = true;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const unsigned long long gv = __hip_atomic_load(gp + 64 * k, RLX_AGENT);
-          val[k] = (unsigned)gv;
-          good &= (unsigned)(gv >> 32) == tag;
-        }
-        if (__all(good) || !ok) break;
-        ch_sleep();
-        if ((++spins & 255u) == 0) {
-          if (*dead) { ok = false; break; }
-          if ((long long)wall_clock64() > deadline) { *dead = 1; ok = false; break; }
+        const unsigned long long gv = __hip_atomic_load(hp, RLX_AGENT);
+        if (__all((unsigned)(gv >> 32) == tag) || !ok) break;
+        idle();
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 127u) == 0) {
+          if (__builtin_amdgcn_readfirstlane(*dead)) ok = false;
+          else if (__builtin_amdgcn_readfirstlane((int)((long long)wall_clock64() > deadline))) { *dead = 1; ok = false; }
         }
       }
+    }
+    unsigned pend = 0;                                 // bit j: chunk cw + 3 j still incomplete
 #pragma unroll
-      for (int k = 0; k < 16; ++k) stage[c * 1024 + lane + 64 * k] = val[k];
+    for (int j = 0; j < NCH; ++j) pend |= (cw + 3 * j < chunks) ? (1u << j) : 0u;
+    unsigned spins = 0;
+    while (pend) {
+      unsigned val[NCH][16];
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+        if (pend & (1u << j)) {
+          gu64* gp = g + (size_t)(cw + 3 * j) * 1024 + lane;
+          bool good = true;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const unsigned long long gv = __hip_atomic_load(gp + 64 * k, RLX_AGENT);
+            val[j][k] = (unsigned)gv;
+            good &= (unsigned)(gv >> 32) == tag;
+          }
+          if (__all(good) || !ok) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) stage[(cw + 3 * j) * 1024 + lane + 64 * k] = val[j][k];
+            pend &= ~(1u << j);
+          }
+        }
+      if (!pend) break;
+      ch_sleep();
+      if ((++spins & 255u) == 0) {
+        if (__builtin_amdgcn_readfirstlane(*dead)) ok = false;
+        else if (__builtin_amdgcn_readfirstlane((int)((long long)wall_clock64() > deadline))) { *dead = 1; ok = false; }
+      }
     }
     ++gath_no;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add((unsigned*)(fl + F_GATH), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add((lds_u*)(fl + F_GATH), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (ok && !lds_wait_ge(fl + F_GATH, 3u * gath_no, deadline, dead)) ok = false;
     asm volatile("" ::: "memory");
   };
@@ -347,7 +399,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   // pieces -- lane l's piece kc is sums-of-squares group 64 kc + l of the GEMV family (8 consecutive columns = one
   // workgroup's rows there).  FMA4: the producer summed its rows as two 4-row FMA chains (down), else 8 rounded squares (o)
   float inv = 1.f;                                     // 1/rms of this lane's token (row t of the wave)
-  auto build_x = [&](const char* st, const u32x4 (&wn)[4], auto fma4) {
+  auto build_x = [&](const lds_char* st, const u32x4 (&wn)[4], auto fma4) {
     constexpr bool FMA4 = decltype(fma4)::value;
     float ssum[TT];
 #pragma unroll
@@ -355,7 +407,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
       float grp[4];
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        const u32x4 hv = *(const u32x4*)(st + t * 4096 + kc * 1024 + lane * 16);
+        const u32x4 hv = *(const __attribute__((address_space(3))) u32x4*)(st + t * 4096 + kc * 1024 + lane * 16);
         float e[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { e[2 * q] = lo_f<P>(hv[q]); e[2 * q + 1] = hi_f<P>(hv[q]); }
@@ -384,15 +436,17 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     inv = rsqrtf(ch_fold<TT>(ssum) / (float)a.H + a.eps);
   };
 
-  unsigned* stH = (unsigned*)(smem + a.off_sth);
-  unsigned* stA = (unsigned*)(smem + a.off_sta);
+  lds_u* stH = (lds_u*)((lds_char*)smem + a.off_sth);
+  lds_u* stA = (lds_u*)((lds_char*)smem + a.off_sta);
+  u32x4 pre[2][4][4];                                  // slots held in registers across an edge (gate/up; then the q/k/v slot)
 
   if (a.front) {
     // ================================================================= o-projection + residual -> h1 granules
     for (int k = cw; k < s_o; k += 3) {                // one step per consumer at most (2 slots)
-      const char* sp = wait_slot(gslot + k);
+      u32x4 wr[4][4];
       float acc[4];
-      rows4(sp, gslot + k, acc);
+      load4(gslot + k, wr);
+      compute4(wr, acc);
       if (fin) {
         const int n0 = orow0 + 4 * sa_o;
         const float r0 = lo_f<P>(h0v[0]), r1 = hi_f<P>(h0v[0]), r2 = lo_f<P>(h0v[1]), r3 = hi_f<P>(h0v[1]);
@@ -420,21 +474,28 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
       nwd[q] = __builtin_amdgcn_raw_buffer_load_b16(rnn, (orow0 + sa_d[q]) * 2, 0, 0);
     }
     load_pos();
-    gather(a.g_h1, T * (a.H / 2048), tag_base | 1u, stH);
+    // this consumer's first two gate/up slots go to registers BEFORE the edge: six ring slots return to the loader
+    const int gu0 = gslot + cw, gu1 = gslot + cw + 3;
+    if (cw < s_gu) load4(gu0, pre[0]);                 // landed long ago
+    bool have1 = !(cw + 3 < s_gu);
+    auto try_pre1 = [&]() {                            // the second one as soon as it has landed, without holding up the sweep
+      if (!have1 && __builtin_amdgcn_readfirstlane(fl[F_LANDED + gu1 % R]) >= (unsigned)gu1 + 1u) { load4(gu1, pre[1]); have1 = true; }
+    };
+    gather(std::integral_constant<int, 1>{}, a.g_h1, T * (a.H / 2048), tag_base | 1u, stH, try_pre1);
+    if (!have1) { load4(gu1, pre[1]); have1 = true; }
     CH_STAMP();                                        // 2: h1 gathered
     if (a.tail) load_rope();                           // pos arrived microseconds ago; lands during gate/up
-    build_x((const char*)stH, wn2, std::false_type{});
+    build_x((const lds_char*)stH, wn2, std::false_type{});
     float h1d[3] = {0.f, 0.f, 0.f};                    // h1 at this consumer's down rows (lane 16 t: token t)
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      if (cw + 3 * q < s_dn && fin) h1d[q] = P::to_f(((const u16*)stH)[tl * a.H + orow0 + sa_d[q]]);
+      if (cw + 3 * q < s_dn && fin) h1d[q] = P::to_f(((const __attribute__((address_space(3))) u16*)stH)[tl * a.H + orow0 + sa_d[q]]);
     // ================================================================= gate/up + SiLU -> act granules
     CH_STAMP();                                        // 3: gate/up operand built
-    for (int k = cw; k < s_gu; k += 3) {
+    auto gu_step = [&](int k, const u32x4 (&wr)[4][4]) {
       const int sa = (k + cu) % s_gu;
-      const char* sp = wait_slot(gslot + k);
       float acc[4];
-      rows4(sp, gslot + k, acc);
+      compute4(wr, acc);
       if (fin) {
         const float iv = inv;
         const float g0 = rnd_prod<P>(acc[0], iv), u0 = rnd_prod<P>(acc[1], iv);
@@ -444,10 +505,34 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
         __hip_atomic_store(a.g_act + (size_t)tl * (a.I / 2) + m0 / 2,
                            ((unsigned long long)(tag_base | 2u) << 32) | pack2<P>(a0, a1), RLX_AGENT);
       }
+    };
+    if (cw < s_gu) gu_step(cw, pre[0]);
+    if (cw + 3 < s_gu) gu_step(cw + 3, pre[1]);
+    for (int k = cw + 6; k < s_gu; k += 3) {
+      u32x4 wr[4][4];
+      load4(gslot + k, wr);
+      gu_step(k, wr);
     }
     gslot += s_gu;
     CH_STAMP();                                        // 4: gate/up slots done
-    gather(a.g_act, T * (a.I / 2048), tag_base | 2u, stA);
+    // the first two down rows of this consumer go to registers before the edge (as above)
+    u32x4 dpre[2][16];
+    auto load16 = [&](int gi, u32x4 (&w16)[16]) {
+      const lds_char* sp = wait_slot(gi);
+#pragma unroll
+      for (int kc = 0; kc < 16; ++kc) w16[kc] = *(const __attribute__((address_space(3))) u32x4*)(sp + kc * 1024 + lane * 16);
+      free_slot(gi);
+    };
+    const int dn0 = gslot + cw, dn1 = gslot + cw + 3;
+    bool dhave0 = !(cw < s_dn), dhave1 = !(cw + 3 < s_dn);
+    auto try_dpre = [&]() {
+      if (!dhave0 && __builtin_amdgcn_readfirstlane(fl[F_LANDED + dn0 % R]) >= (unsigned)dn0 + 1u) { load16(dn0, dpre[0]); dhave0 = true; }
+      if (dhave0 && !dhave1 && __builtin_amdgcn_readfirstlane(fl[F_LANDED + dn1 % R]) >= (unsigned)dn1 + 1u) { load16(dn1, dpre[1]); dhave1 = true; }
+    };
+    try_dpre();
+    gather(std::integral_constant<int, (TT * 4 + 2) / 3>{}, a.g_act, T * (a.I / 2048), tag_base | 2u, stA, try_dpre);
+    if (!dhave0) { load16(dn0, dpre[0]); dhave0 = true; }
+    if (!dhave1) { load16(dn1, dpre[1]); dhave1 = true; }
     CH_STAMP();                                        // 5: act gathered
     // ================================================================= down-projection + residual -> h2 (plain + granules)
     // one K = 8192 row per slot; the operand stays in LDS staging (lane l: k = 512 kc + 8 l .. + 7) and is read with the
@@ -458,18 +543,21 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
       const int k = cw + 3 * q;
       if (k >= s_dn) break;
       const int sa = sa_d[q];
-      const char* sp = wait_slot(gslot + k);
+      const lds_char* sp = q < 2 ? (const lds_char*)smem : wait_slot(gslot + k);
       float tot = 0.f;                                 // row t of the wave: token t
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         u32x4 wr[8], xa[TT][8];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) wr[kc] = *(const u32x4*)(sp + (8 * hf + kc) * 1024 + lane * 16);
+        for (int kc = 0; kc < 8; ++kc) {
+          if (q < 2) wr[kc] = dpre[q < 2 ? q : 0][8 * hf + kc];
+          else wr[kc] = *(const __attribute__((address_space(3))) u32x4*)(sp + (8 * hf + kc) * 1024 + lane * 16);
+        }
 #pragma unroll
         for (int t = 0; t < TT; ++t)
 #pragma unroll
-          for (int kc = 0; kc < 8; ++kc) xa[t][kc] = *(const u32x4*)((const char*)stA + t * 16384 + (8 * hf + kc) * 1024 + lane * 16);
-        if (hf == 1) free_slot(gslot + k);
+          for (int kc = 0; kc < 8; ++kc) xa[t][kc] = *(const __attribute__((address_space(3))) u32x4*)((const lds_char*)stA + t * 16384 + (8 * hf + kc) * 1024 + lane * 16);
+        if (q >= 2 && hf == 1) free_slot(gslot + k);
         float part[2][TT];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -497,13 +585,13 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
         a.h[off] = P::from_f(h2);
         if (a.next_norm) a.hw[off] = P::from_f(h2 * P::to_f(nwd[q]));
         fl[F_HV + sa * 4 + tl] = (unsigned)P::from_f(h2);
-        ((volatile float*)fl)[F_SQ + sa * 4 + tl] = h2;
+        ((lds_vf*)fl)[F_SQ + sa * 4 + tl] = h2;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       unsigned oldp = 0, oldc = 0;
       if (lane == 0) {
-        oldp = __hip_atomic_fetch_add((unsigned*)(fl + F_PAIR + (sa >> 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        oldc = __hip_atomic_fetch_add((unsigned*)(fl + F_SQCNT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        oldp = __hip_atomic_fetch_add((lds_u*)(fl + F_PAIR + (sa >> 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        oldc = __hip_atomic_fetch_add((lds_u*)(fl + F_SQCNT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       oldp = __builtin_amdgcn_readfirstlane(oldp);
       oldc = __builtin_amdgcn_readfirstlane(oldc);
@@ -514,7 +602,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
                            ((unsigned long long)(tag_base | 3u) << 32) | lo | (hi << 16), RLX_AGENT);
       }
       if (oldc == (unsigned)s_dn - 1 && fin && a.ssq) {   // last finisher: the CU's sums-of-squares group, gv_kernel's order
-        volatile float* sq = (volatile float*)fl + F_SQ;
+        lds_vf* sq = (lds_vf*)fl + F_SQ;
         float s0 = sq[0 * 4 + tl] * sq[0 * 4 + tl], s1 = sq[4 * 4 + tl] * sq[4 * 4 + tl];
         asm volatile("" : "+v"(s0), "+v"(s1));
 #pragma unroll
@@ -529,9 +617,16 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     gslot += s_dn;
     CH_STAMP();                                        // 6: down slots done
     if (a.tail) {
-      gather(a.g_h2, T * (a.H / 2048), tag_base | 3u, stH);
+      const int q0 = gslot + cw;
+      bool qhave = !(cw < s_q);
+      auto try_q = [&]() {                             // this consumer's q/k/v slot, ahead of the edge
+        if (!qhave && __builtin_amdgcn_readfirstlane(fl[F_LANDED + q0 % R]) >= (unsigned)q0 + 1u) { load4(q0, pre[0]); qhave = true; }
+      };
+      try_q();
+      gather(std::integral_constant<int, 1>{}, a.g_h2, T * (a.H / 2048), tag_base | 3u, stH, try_q);
+      if (!qhave) { load4(q0, pre[0]); qhave = true; }
       CH_STAMP();                                      // 7: h2 gathered
-      build_x((const char*)stH, wnn, std::true_type{});
+      build_x((const lds_char*)stH, wnn, std::true_type{});
     }
     // the next launch reads the epoch after this one has ended; CU 0 has seen every CU's granules by now
     if (cu == 0 && cw == 0 && lane == 0 && a.epoch) __hip_atomic_store(a.epoch, (tag_base >> 2) + 1u, RLX_AGENT);
@@ -546,9 +641,14 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   if (a.tail) {
     // ================================================================= q/k/v + RoPE + KV append (plain stores)
     for (int k = cw; k < s_q; k += 3) {                // one step per consumer (3 slots)
-      const char* sp = wait_slot(gslot + k);
       float acc[4];
-      rows4(sp, gslot + k, acc);
+      if (a.front) {
+        compute4(pre[0], acc);
+      } else {
+        u32x4 wr[4][4];
+        load4(gslot + k, wr);
+        compute4(wr, acc);
+      }
       if (!fin) continue;
       const float iv = inv;
       const int D = a.D, half = D / 2;
@@ -609,7 +709,7 @@ extern "C" int umb_chain_ok(int T, int H, int I, int NQKV, int D, int has_bias) 
 }
 
 extern "C" size_t umb_chain_xchg_bytes(int Tmax, int H, int I) {
-  return (size_t)Tmax * (H / 2 + I / 2 + H / 2) * 8 + 256;
+  return (size_t)Tmax * (H / 2 + I / 2 + H / 2) * 8 + 256;       // granules | epoch word, status word
 }
 
 static size_t chain_tail_off(int Tmax, int H, int I) { return (size_t)Tmax * (H / 2 + I / 2 + H / 2) * 8; }
