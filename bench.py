@@ -95,7 +95,10 @@ def dist_env():
 
 def share_gpu() -> bool:
     """tests on a one-GPU box: every rank drives cuda:0 and the ranks talk over gloo (host staged)"""
-    return os.environ.get("UMB_BENCH_SHARE_GPU", "0") == "1"
+    on = os.environ.get("UMB_BENCH_SHARE_GPU", "0") == "1"
+    if on:
+        os.environ["UMB_CHAIN"] = "0"        # the persistent chain needs the device to itself (csrc/chain.hip)
+    return on
 
 
 def self_launch(args):

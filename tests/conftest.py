@@ -30,3 +30,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- parity facts: numbers a test MEASURED (exact arg-max agreements, near-tie positions, accept lengths) are printed in
+# the terminal summary -- i.e. in the tail of `pytest -q` that the driver keeps -- and written to gpurun_out/parity_facts.json,
+# so a run that passes with 21 of 24 exact tokens can be told from one that passes with 24 of 24.
+_FACTS = {}
+
+
+def report_fact(name: str, value):
+    _FACTS[name] = value
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not _FACTS:
+        return
+    import json
+    terminalreporter.write_sep("=", "parity facts (measured by the tests above)")
+    for k in sorted(_FACTS):
+        terminalreporter.write_line(f"{k}: {json.dumps(_FACTS[k])}")
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_facts.json"), "w") as f:
+            json.dump(_FACTS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -95,6 +95,7 @@ struct ChainArgs {
   float eps;
   unsigned off_sth, off_sta;
   long long timeout_ticks;
+  int hint;                           // 1: poll one 512-byte piece before the full sweeps (UMB_CHAIN_HINT=0: experiments)
   int drop_cu;                        // test hook (UMB_CHAIN_TEST_DROP_CU): this workgroup withholds its o-projection granules
   unsigned long long* trace;          // UMB_CHAIN_TRACE builds only
 };
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   // from 4 - 16 producers, the others finish around the same time -- the tags of the full sweep decide.
   auto gather = [&](auto nch, gu64* g, int chunks, unsigned tag, lds_u* stage, auto&& idle) {
     constexpr int NCH = decltype(nch)::value;
-    if (cw < chunks) {
+    if (cw < chunks && a.hint) {
       gu64* hp = g + (size_t)cw * 1024 + (size_t)((cu + 5 * cw) & 15) * 64 + lane;
       unsigned spins = 0;
       for (;;) {
@@ -761,6 +762,8 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
   a.timeout_ticks = (etm ? atoll(etm) : 20ll) * 100000ll;
   const char* edr = getenv("UMB_CHAIN_TEST_DROP_CU");
   a.drop_cu = edr ? atoi(edr) : -1;
+  static const int hint_on = getenv("UMB_CHAIN_HINT") ? atoi(getenv("UMB_CHAIN_HINT")) : 1;
+  a.hint = hint_on;
 #ifdef UMB_CHAIN_TRACE
   const char* etr = getenv("UMB_CHAIN_TRACE_PTR");
   static int trace_seq = 0;                             // one region per launch (64 regions of [256][4][32] stamps)

@@ -1605,8 +1605,12 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   // rate, scripts/probe/valu_probe.hip), 70B gate/up 47.9 vs 52.6 us on the same box.  It computes the real-valued
   // (q - z) * s model without rounding each weight to fp16 first: within 2^-11 relative per weight of the reference's
   // awq_ext-dequantised weights (tests: 2e-3 of the row scale), and what the low-latency family always did.
-  // T > 64 (matrix-pipe bound verify GEMMs) and UMB_AWQ_EXACT=1: exact dequant, W = fp16((q - z) * s) bit for bit.
-  static const bool awq_exact = getenv("UMB_AWQ_EXACT") != nullptr;
+  // T > 64 (matrix-pipe bound verify GEMMs) and UMB_DEQUANT=exact (or the older UMB_AWQ_EXACT=1): exact dequant,
+  // W = fp16((q - z) * s) bit for bit, for EVERY row count -- one int4 arithmetic from the T = 1 row to the widest verify,
+  // as the reference's single awq_ext kernel has (awq_utils.py:67-77).  Read per call (launch arguments are frozen into a
+  // captured graph anyway), so a process can hold both forms.  The folded form exists for <= 64 rows only.
+  const char* dq = getenv("UMB_DEQUANT");
+  const bool awq_exact = (dq && dq[0] == 'e') || getenv("UMB_AWQ_EXACT") != nullptr;
   if (awq && dtype == UMB_F16 && (awq_exact || T > 64))
     return launch_tt<F16, 2>(wpacked, meta, (const u16*)x, ldx, (float*)out, T, N, K, R, S, epi, fx, st, tb);
   DISPATCH_DTYPE(dtype, {

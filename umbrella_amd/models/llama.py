@@ -474,11 +474,12 @@ class Llama(LLMBase):
     def _chain_setup(self):
         """Persistent chain (csrc/chain.hip): with the draft role on and a covered shape (umb_chain_ok: 1B-class dense
         models, <= 3 rows, no q/k/v bias, a 256-CU device) the <= 3-row forwards run as tree attention + ONE persistent
-        launch per layer.  The launch needs every workgroup resident, i.e. this process alone on the device.
-        UMB_CHAIN=1 switches it on (default off while the five GEMV launches are the faster schedule: DESIGN.md 7b)."""
+        launch per layer.  The launch needs every workgroup resident, i.e. this process alone on the device:
+        UMB_CHAIN=0 keeps the five GEMV launches (runs that share one GPU between processes set it; a launch that cannot
+        complete gives up after 20 ms and the engines raise on its status word)."""
         c = self.config
         lib = _lib.load()
-        on = (getattr(self, "gemv", False) and os.environ.get("UMB_CHAIN", "0") != "0" and self._tp is None
+        on = (getattr(self, "gemv", False) and os.environ.get("UMB_CHAIN", "1") != "0" and self._tp is None
               and self._off is None and hasattr(self, "_ws")
               and all(getattr(ln, "w_rows", None) is not None for lins in self.layers for ln in lins.values()))
         has_bias = int(any(getattr(st, "qkv_bias", None) for st in self._layer_structs))
@@ -490,8 +491,11 @@ class Llama(LLMBase):
                 _lib.check(lib.umb_chain_xchg_init(self._chain_xchg.data_ptr(), 4, c.hidden_size, c.intermediate_size,
                                                    _lib.stream_ptr()), "umb_chain_xchg_init")
             self._ws.chain_xchg = self._chain_xchg.data_ptr()
+            off = 4 * (c.hidden_size // 2 + c.intermediate_size // 2 + c.hidden_size // 2) * 8 + 64
+            self.chain_status_word = self._chain_xchg[off:off + 4].view(torch.int32)     # device view (engines copy it out)
         elif hasattr(self, "_ws"):
             self._ws.chain_xchg = 0
+            self.chain_status_word = None
         self.chain = bool(hasattr(self, "_ws") and self._ws.chain_xchg)
 
     def chain_status(self) -> int:

@@ -214,6 +214,12 @@ class HipEngine(BaseEngine):
                   self.eos_dev, len(self.eos_tokens), self.res, self.path)
         self.draft_model.kv_cache.compact(self.res, self.path, self.max_path)
         self.target_model.kv_cache.compact(self.res, self.path, self.max_path)
+        st = getattr(self.draft_model, "chain_status_word", None)
+        if st is not None:                    # the persistent chain's give-up word rides along with the accept result
+            self.res[7:8].copy_(st)
+        pw = getattr(self.target_model, "peer_status_word", None)
+        if pw is not None:                    # and the tensor-parallel peer path's (csrc/tp.hip)
+            self.res[6:7].copy_(pw)
         self.res_host.copy_(self.res, non_blocking=True)
 
     def _iteration_launch(self):
@@ -271,6 +277,15 @@ class HipEngine(BaseEngine):
     def _finish_iteration(self) -> bool:
         torch.cuda.current_stream().synchronize()
         keep, bonus, eos, n_new, raw = self.res_host[:5].tolist()
+        if self.res_host[6] != 0:
+            st = int(self.res_host[6]) & 0xffffffff
+            self.target_model.peer.reset_status()
+            raise RuntimeError(f"tensor parallel: a peer never published its tile (status {st:#x}); the tokens of this "
+                               "iteration are invalid -- the group is out of step or a rank died")
+        if self.res_host[7] != 0:
+            raise RuntimeError(f"the draft model's persistent chain gave up on a hand-off (status {int(self.res_host[7]) & 0xffffffff:#x}): "
+                               "its launches need the whole device (one process per GPU); set UMB_CHAIN=0 to run the draft on "
+                               "the five GEMV launches")
         self.last_accept, self.last_bonus = keep, bonus
         self.num_nodes = n_new
         self.draft_model.kv_cache.kv_offset = n_new
@@ -300,6 +315,11 @@ class HipEngine(BaseEngine):
     def manual_seed(self, seed: int):
         self.seed = seed
         self.rng_state.fill_(seed)
+        u = getattr(self, "uniform_samples", None)
+        if u is not None and getattr(self, "_uniform_arg", None) is None:
+            # the static engine's frozen uniforms are a function of the seed (drawn where the reference draws them,
+            # static:131): a new seed redraws them IN PLACE, so a captured iteration keeps replaying
+            u.copy_(torch.rand(u.shape[0], u.shape[1], generator=torch.Generator().manual_seed(int(seed))))
 
     @torch.inference_mode()
     def reset(self):

@@ -42,12 +42,13 @@ class StaticSpeculationEngine(HipEngine):
         self.growmap_path = kwargs.pop("growmap_path", None)
         self.growmap = kwargs.pop("growmap", None)
         assert self.growmap_path is not None or self.growmap is not None, "Please specify growmap path for static trees"
-        # Stochastic verification.  Default: fresh counter-based draws per (seed, position, node) -- umb_sample_rows.
-        # reference_sampler=True (or an explicit uniform_samples [3, tree_size] tensor): the reference's own draw --
+        # Stochastic verification.  Default (round 5: a drop-in behaves like what it replaces): the reference's own draw --
         # flashinfer's rejection sampler over ONE rand(3, tree_size) tensor taken at initialize() and reused by every
-        # verify (static:131,310) -- so that the same uniforms give the same tokens as the reference, draw for draw.
+        # verify (static:131,310); an explicit uniform_samples [3, tree_size] tensor gives the reference's tokens draw for
+        # draw.  reference_sampler=False: fresh counter-based draws per (seed, position, node) -- umb_sample_rows -- the
+        # distribution-equivalent sampler without the frozen uniforms.
         self._uniform_arg = kwargs.pop("uniform_samples", None)
-        self.reference_sampler = bool(kwargs.pop("reference_sampler", False)) or self._uniform_arg is not None
+        self.reference_sampler = bool(kwargs.pop("reference_sampler", True)) or self._uniform_arg is not None
         self._common_kwargs(kwargs)
         self.config = kwargs
 

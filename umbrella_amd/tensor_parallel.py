@@ -179,6 +179,10 @@ class TPComm:
 
 
 # ------------------------------------------------------------------ direct peer all-reduce (csrc/tp.hip)
+class PeerExchangeUnavailable(RuntimeError):
+    """raised by PeerExchange on EVERY rank of the group when any rank failed to allocate or map (a collective verdict)"""
+
+
 class PeerExchange:
     """The exchange buffers of the direct-xGMI all-reduce: every rank allocates [2][cap] floats + one flag line
     (fine-grained device memory where the runtime allows), hands its interprocess handle round the group once, maps the
@@ -194,23 +198,43 @@ class PeerExchange:
         assert 2 <= self.world <= _lib.TP_MAX_RANKS
         self.cap = (int(cap_floats) + 63) // 64 * 64
         nbytes = 2 * self.cap * 4 + self.FLAG_BYTES
+        # Every step that can fail on ONE rank (allocation, mapping a peer's handle) is followed by a group-wide
+        # agreement: a rank that raised on its own used to leave the others inside all_gather_object / the closing barrier,
+        # or on the peer path against a rank already on the collective hook.  Every rank reaches every collective below
+        # whatever happened locally; the path is enabled only if all ranks succeeded, otherwise everybody cleans up and
+        # raises the same PeerExchangeUnavailable (the caller then takes the hook on ALL ranks).
+        self.base, self.fine_grained, self.peer_ptrs, self._opened = 0, False, [0] * self.world, []
         with torch.cuda.device(device):
-            base, fg = C.c_void_p(0), C.c_int(0)
             handle = (C.c_ubyte * 64)()
-            _lib.check(lib.umb_tp_xchg_alloc(nbytes, C.byref(base), handle, C.byref(fg)), "umb_tp_xchg_alloc")
-            self.base, self.fine_grained = base.value, bool(fg.value)
+            err = None
+            try:
+                base, fg = C.c_void_p(0), C.c_int(0)
+                _lib.check(lib.umb_tp_xchg_alloc(nbytes, C.byref(base), handle, C.byref(fg)), "umb_tp_xchg_alloc")
+                self.base, self.fine_grained = base.value, bool(fg.value)
+            except Exception as e:
+                err = e
             handles = [None] * self.world
-            dist.all_gather_object(handles, (self.rank, bytes(handle), os.getpid()), group=comm.group)
-            self.peer_ptrs, self._opened = [0] * self.world, []
-            for r, hb, pid in handles:
-                if r == self.rank:
-                    self.peer_ptrs[r] = self.base
-                    continue
-                p = C.c_void_p(0)
-                buf = (C.c_ubyte * 64).from_buffer_copy(hb)
-                _lib.check(lib.umb_tp_xchg_open(buf, C.byref(p)), f"umb_tp_xchg_open(rank {r})")
-                self.peer_ptrs[r] = p.value
-                self._opened.append(p.value)
+            dist.all_gather_object(handles, (self.rank, bytes(handle), os.getpid(), err is None), group=comm.group)
+            if all(h[3] for h in handles):
+                try:
+                    for r, hb, pid, _ok in handles:
+                        if r == self.rank:
+                            self.peer_ptrs[r] = self.base
+                            continue
+                        p = C.c_void_p(0)
+                        buf = (C.c_ubyte * 64).from_buffer_copy(hb)
+                        _lib.check(lib.umb_tp_xchg_open(buf, C.byref(p)), f"umb_tp_xchg_open(rank {r})")
+                        self.peer_ptrs[r] = p.value
+                        self._opened.append(p.value)
+                except Exception as e:
+                    err = e
+            elif err is None:
+                err = RuntimeError("a peer rank could not allocate its exchange buffer")
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err is None, group=comm.group)
+            if not all(oks):
+                self.close()
+                raise PeerExchangeUnavailable(str(err) if err is not None else "a peer rank could not map the exchange buffers")
         self.words = torch.zeros(64, dtype=torch.int32, device=device)       # epoch | arrive | status, 64 bytes apart
         d = _lib.UmbTPPeer()
         d.rank, d.world, d.cap, d.spin_limit = self.rank, self.world, self.cap, int(os.environ.get("UMB_TP_SPIN", "0"))
@@ -225,12 +249,15 @@ class PeerExchange:
         return int(self.words[32].item()) & 0xffffffff
 
     def close(self):
-        for p in self._opened:
+        for p in getattr(self, "_opened", []):
             self.lib.umb_tp_xchg_close(p)
         self._opened = []
-        if self.base:
+        if getattr(self, "base", 0):
             self.lib.umb_tp_xchg_free(self.base)
             self.base = 0
+
+    def reset_status(self):
+        self.words[32] = 0
 
 
 # ------------------------------------------------------------------ the sharded target
@@ -397,10 +424,19 @@ class TensorParallelLlama:
             self.peer_disabled = True
         return ok
 
+    @property
+    def peer_status_word(self):
+        """device view of the peer path's sticky give-up word (None without a peer exchange): the engines copy it out with
+        every iteration's accept result, so a reduce that gave up is raised at the next host sync, not at the next clear()"""
+        if self.peer is None or getattr(self, "peer_disabled", False):
+            return None
+        return self.peer.words[32:33]
+
     def _check_peer(self):
         if self.peer is not None and not getattr(self, "peer_disabled", False):
             st = self.peer.status()
             if st:
+                self.peer.reset_status()             # sticky on the device, not across the exception
                 raise RuntimeError(f"tensor parallel: a peer never published its tile (status {st:#x}: row block {st & 0xffff}); "
                                    "the group is out of step or a rank died")
 
@@ -443,8 +479,10 @@ class TensorParallelLlama:
         self.kv_cache.gather_kv_incremental(indices, offset)
 
     def clear(self):
-        self._check_peer()
-        self.m.clear()
+        try:
+            self._check_peer()
+        finally:
+            self.m.clear()                           # the caches are cleared whatever the peer path reported
 
     def weight_bytes(self):
         return self.m.weight_bytes()
