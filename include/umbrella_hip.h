@@ -397,7 +397,8 @@ typedef int (*umb_allreduce_fn)(void* ctx, float* buf, int64_t count, umb_stream
  * no ring: two launches in the rank's own stream where the single-GPU schedule has two (sum / reduce).
  * slot[r], flag[r]: rank r's buffer / flag as mapped HERE (own entries: the local pointers).  epoch, arrive, status:
  * local zero-initialised device words (calls so far; self-resetting block counter; 0 or 0xDEADxxxx after a peer failed
- * to arrive within spin_limit polls, 0: ~2 s). */
+ * to arrive within spin_limit polls, 0: ~70 s).  status points at a zero-initialised 128-byte line: the word 64 bytes
+ * behind it is the library's local release word (block 0 polls the peers, the other row blocks wait on it). */
 #define UMB_TP_MAX_RANKS 16
 typedef struct UmbTPPeer {
   int32_t rank, world;

@@ -73,6 +73,42 @@ def test_two_stage_pipeline_equals_single_process():
     assert a == ra and b == rb
 
 
+def test_eight_stage_pipeline_equals_single_process():
+    """BASELINE config 5's shape -- EIGHT stages -- on the one GPU a test box has: eight processes, two of the 1B's 16
+    layers each, seven gloo hops per forward (host staged), per-stage hipGraphs; token ids == the single-process engine's.
+    (RCCL send / recv between devices stays unmeasured here: README.)"""
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1"); os.environ["UMB_CHAIN"] = "0"
+    from umbrella_amd.sequoia_utils import generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    ref = StaticSpeculationEngine(NAME, NAME, dtype=torch.float16, device="cuda:0", growmap=generate_sequoia_tree(3, 4),
+                                  max_length=512, exit_layer=4, safe_buffer=16, tokenizer=IdTokenizer())
+    ref.initialize()
+    ra = ref.generate(input_ids=PROMPT, max_new_tokens=20)["generated_tokens"]
+    rb = ref.generate(input_ids=(PROMPT * 5)[:70], max_new_tokens=12)["generated_tokens"]
+    del ref
+    torch.cuda.empty_cache()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pp_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    try:
+        a, b, stage_layers = q.get(timeout=400)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert stage_layers == 2                                          # 16 layers, 2 per stage
+    assert a == ra and b == rb
+
+
 DYN = dict(width=8, num_beams=8, depth=4, temperature=0.7, topp=0.9, topk=16, repetition_penalty=1.05)
 
 

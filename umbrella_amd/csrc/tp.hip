@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256) void tp_publish_kernel(const float* __restrict
 }
 
 // ---- reduce: h <- round(round(sum_r tile_r) + h) ; xn <- rmsnorm(h) * w   (umb_reduce_residual_norm over peer tiles)
-template <typename P>
+// W: the loads of a row are unrolled to the smallest of 2 / 4 / 8 / 16 that covers `world` (round 4 always issued 16
+// predicated loads per element).  ONE block polls the peers' flags over the link -- block 0, one lane per peer -- and
+// releases the other T - 1 through a LOCAL word (`seen`, 64 bytes behind the status word): round 4 had T x (world - 1)
+// lanes spinning on remote memory.
+template <typename P, int W>
 __global__ __launch_bounds__(1024) void tp_reduce_residual_norm_kernel(TpPtrs pp, int world, long cap,
                                                                        const unsigned* __restrict__ epoch_p, int T, int N,
                                                                        const u16* residual, u16* h_out,
@@ -73,27 +77,41 @@ __global__ __launch_bounds__(1024) void tp_reduce_residual_norm_kernel(TpPtrs pp
   __shared__ int gave_up;
   const int t = blockIdx.x;
   const unsigned e = *epoch_p;                             // the publish launch just ahead of this one made it e
+  unsigned* seen = status + 16;                            // local release word (zero-initialised with the status line)
   if (threadIdx.x == 0) gave_up = 0;
   __syncthreads();
-  if (threadIdx.x < world) {
+  if (t == 0) {
+    if (threadIdx.x < world) {
+      long spins = 0;
+      while (__hip_atomic_load(pp.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e > 0x7fffffffu) {   // flag < e (wrap safe)
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > spin_limit) { gave_up = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (gave_up) atomicExch(status, 0xDEAD0000u | (unsigned)t);      // a peer never arrived: say so (the host raises) ...
+      __hip_atomic_store(seen, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and let the other rows go either way
+    }
+  } else if (threadIdx.x == 0) {
     long spins = 0;
-    while (__hip_atomic_load(pp.flag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e > 0x7fffffffu) {   // flag < e (wrap safe)
+    while (__hip_atomic_load(seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - e > 0x7fffffffu) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > spin_limit) { gave_up = 1; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: nothing cached from the peers' tiles survives
   }
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: nothing cached from the peers' tiles survives
   __syncthreads();
-  if (gave_up) {                                           // a peer never arrived: say so and leave (the host raises)
-    if (threadIdx.x == 0) atomicExch(status, 0xDEAD0000u | (unsigned)t);
+  if (gave_up) {
+    if (threadIdx.x == 0 && t != 0) atomicExch(status, 0xDEAD0000u | (unsigned)t);
     return;
   }
   const long slot_off = (long)(e & 1u) * cap + (long)t * N;
   float ss = 0.f;
   for (int i = threadIdx.x * 4; i < N; i += 1024 * 4) {
-    f32x4 v[UMB_TP_MAX_RANKS];
+    f32x4 v[W];
 #pragma unroll
-    for (int r = 0; r < UMB_TP_MAX_RANKS; ++r) {
+    for (int r = 0; r < W; ++r) {
       if (r < world) {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pp.slot[r] + slot_off), 0, (unsigned)N * 4u, 0x00020000);
         v[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, i * 4, 0, 17));   // sc0 sc1: system coherent
@@ -101,7 +119,7 @@ __global__ __launch_bounds__(1024) void tp_reduce_residual_norm_kernel(TpPtrs pp
     }
     f32x4 a = v[0];
 #pragma unroll
-    for (int r = 1; r < UMB_TP_MAX_RANKS; ++r)
+    for (int r = 1; r < W; ++r)
       if (r < world) a += v[r];                                 // rank order: the same bits on every rank
     float x0 = rnd<P>(a[0]), x1 = rnd<P>(a[1]), x2 = rnd<P>(a[2]), x3 = rnd<P>(a[3]);
     if (residual) {
@@ -153,11 +171,19 @@ extern "C" int umb_tp_reduce_residual_norm(const UmbTPPeer* p, int T, int N, con
   TpPtrs pp = {};
   for (int r = 0; r < p->world; ++r) { pp.slot[r] = p->slot[r]; pp.flag[r] = p->flag[r]; }
   const size_t sm = 64 + (size_t)N * 2;
-  const long spin = p->spin_limit > 0 ? p->spin_limit : (1l << 24);      // x ~0.13 us per s_sleep 2 round: ~2 s
+  // x ~0.13 us per s_sleep 2 round: ~70 s by default.  A collective would simply wait; the bound only keeps a dead peer from
+  // hanging the device for ever, and the engines read the status word with every iteration's accept result (round 5).
+  const long spin = p->spin_limit > 0 ? p->spin_limit : (1l << 29);
+#define TP_GO(WV) hipLaunchKernelGGL((tp_reduce_residual_norm_kernel<P, WV>), dim3(T), dim3(1024), sm, st, pp, p->world,       \
+                                     (long)p->cap, p->epoch, T, N, (const u16*)residual, (u16*)h_out, (u16*)xn_out,             \
+                                     (const u16*)w, eps, p->status, spin)
   DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((tp_reduce_residual_norm_kernel<P>), dim3(T), dim3(1024), sm, st, pp, p->world, (long)p->cap, p->epoch,
-                       T, N, (const u16*)residual, (u16*)h_out, (u16*)xn_out, (const u16*)w, eps, p->status, spin);
+    if (p->world <= 2) TP_GO(2);
+    else if (p->world <= 4) TP_GO(4);
+    else if (p->world <= 8) TP_GO(8);
+    else TP_GO(16);
   })
+#undef TP_GO
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

@@ -507,8 +507,12 @@ class _PipelinedMixin:
     DYNAMIC_MASK = False
 
     def _pp_init(self, stage_model, comm):
-        assert not getattr(self, "reference_sampler", False), \
-            "reference_sampler (frozen uniforms) is a single-GPU static-engine mode: the last pipeline stage draws its own"
+        # the static engine's reference draw (ONE frozen rand(3, T), static:131,310) is a single-GPU mode: here the LAST stage
+        # samples, with its own counter-based draws (umb_sample_rows, same seed / knobs on every stage).  An explicit
+        # uniform_samples tensor cannot be honoured and is refused; the default simply switches to the fresh-draw sampler.
+        assert getattr(self, "_uniform_arg", None) is None, \
+            "uniform_samples (the reference's frozen uniforms) is a single-GPU static-engine mode: the last pipeline stage draws its own"
+        self.reference_sampler = False
         self._stage_model, self._comm = stage_model, comm
         self._in_decode, self._pending = False, False
         self._decode_knobs = None
