@@ -543,11 +543,13 @@ def secondary_configs(device, seed=0):
             ms, acc = sorted(times)[1], (eng.num_nodes - start) / 3
             m = eng.target_model
             streamed = sum(1 for h in m.host_slabs if h is not None) * m.slab_bytes
+            torch.cuda.synchronize()
+            place = m.host_placement()
             return {"config": f"C3: 70B-AWQ layers streamed from pinned host DRAM, num_cache_layers {ncl}, 1B draft, dynamic "
                               "w16/b24/d16 (T=257)", "ms_per_step": round(ms, 1), "accept_len_raw_draft": round(acc, 2),
                     "streamed_GB_per_verify": round(streamed / 1e9, 2), "bound": "host link (PCIe Gen5 x16, 63 GB/s spec)",
                     "achieved_GBs": round(streamed / ms / 1e6, 1), "frac": round(streamed / ms / 1e6 / 63.0, 4),
-                    "step_ms": [round(t, 1) for t in times]}
+                    "step_ms": [round(t, 1) for t in times], "host": place}
         return run
 
     guarded("c2", c2)
@@ -787,6 +789,23 @@ def main():
 
     import __graft_entry__ as ge
     ge.build()
+    if world == 1 and not args.no_secondary and args.workload == "70b-awq+1b":
+        # the offload legs' host arena is claimed NOW -- NUMA-local to the GPU, one pinned registration -- before the
+        # headline's allocations fragment the host (umbrella_amd/models/host_arena.py)
+        try:
+            from umbrella_amd.models import host_arena
+            from umbrella_amd.models.config import KNOWN
+            from umbrella_amd.models.llama import PackedLinear
+            from umbrella_amd.models.synthetic import linear_shapes
+            c70 = KNOWN[T70]
+            sh = linear_shapes(c70)
+            groups = (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), ("self_attn.o_proj",),
+                      ("mlp.gate_proj", "mlp.up_proj"), ("mlp.down_proj",))
+            slab = sum(sum(PackedLinear.packed_bytes(sum(sh[n][0] for n in names), sh[names[0]][1], True)) for names in groups)
+            slot = (slab + host_arena.ALIGN - 1) // host_arena.ALIGN * host_arena.ALIGN
+            host_arena.reserve(c70.num_hidden_layers * slot, device)
+        except Exception as e:                                            # the legs fall back to per-layer pinned tensors
+            print(f"bench: host arena not reserved ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
     eng, gm, acc, dt, tokens, info = headline(args, wl, dtype, device, rank, world, dist, agg_device)
     out = headline_line(args, wl, eng, gm, acc, dt, tokens, info, world)
     accept_len = out["accept_len"]

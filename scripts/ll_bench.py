@@ -234,7 +234,7 @@ for what in sys.argv[1:] or ["1b", "70b", "fwd1b", "fwd70b"]:
         bench_forward("hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4", 16, int(os.environ.get("T70", 13)), torch.float16)
     elif what == "fwd8bawq":
         for T in (int(v) for v in os.environ.get("T8B", "1,2,32").split(",")):
-            bench_forward("hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4", 32, T, torch.float16)
+            bench_forward("hugging-quants/Meta-Llama-3.1-8B-Instruct-AWQ-INT4", int(os.environ.get("L8B", 32)), T, torch.float16)
     elif what == "fwd8b":
         for T in (int(v) for v in os.environ.get("T8B", "31").split(",")):
             bench_forward("meta-llama/Llama-3.1-8B-Instruct", 32, T, torch.bfloat16)

@@ -363,6 +363,13 @@ class Llama(LLMBase):
             wb, mb = PackedLinear.packed_bytes(sum(shapes[n][0] for n in names), shapes[names[0]][1], c.awq)
             slab_bytes += wb + mb
         self.slab_bytes = slab_bytes
+        # host side of the offload path: ONE arena on the GPU's NUMA node, pinned with one registration (models/host_arena.py;
+        # a torch pin_memory() tensor per layer when the arena cannot be had)
+        self._host_arena = None
+        if self.offload and L > self.num_cache_layers:
+            from . import host_arena
+            slot = (slab_bytes + host_arena.ALIGN - 1) // host_arena.ALIGN * host_arena.ALIGN
+            self._host_arena = host_arena.take((L - self.num_cache_layers) * slot, dev)
         self.layers, self.slabs, self.host_slabs, self.norms, self.qkv_biases = [], [], [], [], []
         self._layer_structs = (UmbLayer * L)()
         stream_any = False
@@ -393,7 +400,9 @@ class Llama(LLMBase):
             ls.norm1, ls.norm2 = n1.data_ptr(), n2.data_ptr()
             ls.qkv_bias = qb.data_ptr() if qb is not None else None
             if streamed:
-                host = torch.empty(slab_bytes, dtype=torch.uint8, pin_memory=True)
+                host = self._host_arena.alloc(slab_bytes) if self._host_arena is not None else None
+                if host is None:
+                    host = torch.empty(slab_bytes, dtype=torch.uint8, pin_memory=True)
                 host.copy_(slab)
                 self.host_slabs.append(host)
                 self.slabs.append(None)
@@ -669,6 +678,32 @@ class Llama(LLMBase):
 
     def clear(self):
         self.kv_cache.clear()
+
+    def host_placement(self, copies: int = 8) -> dict:
+        """Where the streamed slabs live on the host and what the link delivers from there: arena / NUMA node
+        (models/host_arena.py) and the rate of `copies` single-slab host-to-device copies on the side stream (GB/s: min,
+        median, max) -- the figures the bench line reports next to the offload step time."""
+        if self._off is None:
+            return {}
+        info = self._host_arena.describe() if self._host_arena is not None else \
+            {"arena": "one torch pin_memory() tensor per layer", "numa_node": None}
+        slabs = [h for h in self.host_slabs if h is not None]
+        rates = []
+        with torch.cuda.stream(self.load_stream):
+            for i in range(copies + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._dev_slabs[i % len(self._dev_slabs)].copy_(slabs[i % len(slabs)], non_blocking=True)
+                e1.record()
+                e1.synchronize()
+                if i:
+                    rates.append(self.slab_bytes / e0.elapsed_time(e1) / 1e6)
+        rates.sort()
+        info["copy_GBs"] = {"min": round(rates[0], 1), "median": round(rates[len(rates) // 2], 1), "max": round(rates[-1], 1)}
+        if self._pf_state is not None:
+            for i in range(len(self._pf_state)):
+                self._pf_state[i] = -1                       # the probe overwrote the device slabs: nothing is prefetched
+        return info
 
     # bytes read from HBM by one forward over all layers + lm_head (algorithmic, for the roofline)
     def weight_bytes(self) -> int:
