@@ -9,7 +9,11 @@
 // set (mask_bits == null: causal, b <= t).
 //
 // Layout (chosen for 16-byte MFMA fragment loads, wave64):
-//   q   [T][Hq][D]            K cache [Hkv][Lmax][D]        V cache TRANSPOSED [Hkv][D][Lmax + UMB_VT_PAD]
+//   q   [T][Hq][D] row-major.  K / V^T caches: one slab per (layer, kv head) of Lmax D / D (Lmax + UMB_VT_PAD) elements whose
+//   INSIDE is in MFMA fragment order since round 4 (common.h: kc_off / vt_off) -- a 32-key tile of K is 2 x D/32 fragments,
+//   of V^T D/16 fragments, 1 KiB each, so every load instruction below reads ONE contiguous KiB.  (Rounds 1-3: row-major
+//   K [Hkv][Lmax][D], V^T [Hkv][D][Lmax + UMB_VT_PAD]; the slab strides are unchanged.)  Key offsets handed to the tile
+//   address (k0 >> 5) are multiples of 32: Lmax % 32 == 0, span and chunk sizes are multiples of 256 (checked at the entry points).
 // Per kv head the T*g query rows (g = Hq/Hkv) form 16-row tiles.  The kernel
 // computes S^T = K Q^T so each lane owns ONE query column: softmax statistics
 // are lane-local (+2 cross-lane xor steps), and the exp'd scores are already in
@@ -538,7 +542,8 @@ extern "C" int umb_tree_attn2(void* out, const void* q, const void* k_cache, con
   static const int one_env = getenv("UMB_ATTN_ONE") ? atoi(getenv("UMB_ATTN_ONE")) : 0;
   int KBK = 2048, single_max = 2048;
   if (counters && Hkv * nqt < 256) {
-    KBK = kbk_env >= 256 && kbk_env % 256 == 0 ? kbk_env : 512;
+    KBK = kbk_env >= 256 && kbk_env % 256 == 0 ? kbk_env : 512;      // multiples of 32 by construction: tile addresses are (k0 >> 5)
+    static_assert(512 % 32 == 0 && 2048 % 32 == 0, "key spans must be whole 32-key tiles");
     while ((Lmax + KBK - 1) / KBK > max_splits && KBK < 2048) KBK *= 2;
     // one span up to 1024 keys.  Row-major cache (first A/B): 768 -- at 512-640 keys two spans +2 us per launch, at 1.6 k keys four spans
     // -5.8 us.  On the fragment-ordered cache a round of the walk is cheaper and the merge is not: T = 13 at 760 / 1000 keys 9.8 / 10.1 us

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           o[q] = pack2<P>(e[2 * q] * lo_f<P>(wn[kc][q]), e[2 * q + 1] * hi_f<P>(wn[kc][q]));
-        x[t][kc] = o;
+        x[t][kc] = o;                                  // (a packed v_pk_mul_f16 here measured no faster and not bit-equal)
         float sg;
         if constexpr (FMA4) {
           float s0 = e[0] * e[0], s1 = e[4] * e[4];

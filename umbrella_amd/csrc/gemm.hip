@@ -1597,6 +1597,7 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
     if (epi == EPI_RESID && (!fx.h || (fx.ssq_out && fx.ssq_out_stride < N / 64))) return UMB_EINVAL;
     if (epi == EPI_QKV && (!fx.pos || !fx.slot || !fx.q_out || !fx.kc || !fx.vt || fx.D % 4 || (fx.ssq_in && fx.ssq_groups % 4)))
       return UMB_EINVAL;
+    if (epi == EPI_QKV && (fx.D % 32 || fx.Lmax % 32 || fx.Lmax < 32)) return UMB_EINVAL;   // fragment-ordered caches: whole tiles
   }
   if (fx.ssq_in && (fx.ssq_groups % 4 || fx.ssq_stride % 4)) return UMB_EINVAL;
   if ((fx.x_fm || fx.out_fm) && T > 64) return UMB_EINVAL;      // FM buffers hold one launch of <= 64 tokens

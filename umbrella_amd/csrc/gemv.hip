@@ -346,6 +346,7 @@ extern "C" int umb_gemv(void* out, const void* x, const void* w_rows, int T, int
   if (epi == GV_RESID && (!a.h || (a.norm_w && !a.hw))) return UMB_EINVAL;
   if (epi == GV_SILU && (!out || N % 2)) return UMB_EINVAL;
   if (epi == GV_QKV && (!a.pos || !a.slot || !a.cosT || !a.sinT || !a.q_out || !a.kc || !a.vt || a.D % 2 || N % 2)) return UMB_EINVAL;
+  if (epi == GV_QKV && (a.D % 32 || a.Lmax % 32 || a.Lmax < 32)) return UMB_EINVAL;   // fragment-ordered caches (common.h): whole 32-key / 32-feature tiles
   // the kernel reads the producer's sums of squares as <= 4 values per lane: 256 groups at most
   if (a.ssq_in && (a.ssq_groups < 1 || a.ssq_groups > 256 || a.ssq_dim <= 0.f)) return UMB_EINVAL;
   const int KS = K / 2048;

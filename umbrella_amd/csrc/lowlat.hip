@@ -524,6 +524,7 @@ extern "C" int umb_gemm_ll(void* out, const void* x_fm, const void* wpacked, con
   if (epi == LL_RESID && (!a.h || (a.norm_w && !a.hw) || (a.ssq_out && a.ssq_out_stride < N / 16 / R))) return UMB_EINVAL;
   if (epi == LL_QKV && (!a.pos || !a.slot || !a.q_out || !a.kc || !a.vt || !a.cosT || !a.sinT || a.D % 4 ||
                         N != (a.Hq + 2 * a.Hkv) * a.D)) return UMB_EINVAL;
+  if (epi == LL_QKV && (a.D % 32 || a.Lmax % 32 || a.Lmax < 32)) return UMB_EINVAL;   // fragment-ordered caches: whole tiles
   if (epi == LL_SILU && N % 32) return UMB_EINVAL;
   const int TT = ll_tt(T);
   auto run = [&](auto tag) -> int {

@@ -533,9 +533,12 @@ __global__ void write_token_kernel(int* tokens_all, const int* n_ptr, const int*
 // one parent are distinct tokens (a top-k); a forced token that one of its SIBLINGS already carries would make two
 // children match the parent's sample and put two nodes of one depth on the accepted path, so that sibling takes the
 // displaced token instead (parents == NULL: no sibling check).  One block; a level holds at most 1024 nodes.
+// ONE lane walks the level (cnt <= 1024): with 64 lanes a sibling could be read by one lane while another rewrote it, and two
+// forced siblings of one parent depended on the lanes' order.
 __global__ void apply_override_kernel(int* tokens_all, const int* n_ptr, const int* tbl, const int* parents, int off, int cnt) {
   const int n = *n_ptr;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < cnt; ++i) {
     const int forced = tbl[off + i];
     if (forced < 0) continue;
     const int old = tokens_all[n + off + i];
