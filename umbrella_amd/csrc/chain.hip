@@ -81,7 +81,7 @@ template <int TT> __device__ __forceinline__ float ch_fold(const float (&v)[TT])
 
 enum { CH_SLOT = 16384, CH_MAXRING = 8 };
 // flag words (u32 index into the flag area)
-enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41,
+enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_SWEEP = 33 /* consumers inside a sweep */, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41,
        F_SQ = 48 /* float [8][4] */, F_HV = 80 /* u32 [8][4] */, F_WORDS = 128 };
 
 struct ChainArgs {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     // the newest 48 pieces have landed.
     const unsigned ring0 = (unsigned)(size_t)(lds_char*)smem;
     const unsigned voff = (unsigned)lane * 16u;
-    const bool lfront = (front_tail & 1) != 0, ltail = (front_tail & 2) != 0;
+    const bool lfront = (front_tail & 1) != 0, ltail = (front_tail & 2) != 0, thin = (front_tail & 4) != 0;
     int i = 0, p = 0;                                  // global slot index, ring position
 #ifdef UMB_CHAIN_TRACE
     unsigned long long full_ticks = 0, full_n = 0;     // ring-full episodes of this loader
@@ -200,7 +200,15 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
                        : "=&s"(keep) : "v"(voff), "s"(sp + j * 4096), "s"(dst + j * 4096) : "memory");
         }
         CH_STAMP();                                    // loader: slot i issued
-        if (i >= 3) {
+        if (thin && __builtin_amdgcn_readfirstlane(fl[F_SWEEP]) != 0) {
+          // consumers of this CU are sweeping an edge: their granule loads queue behind this wave's pieces in the CU's
+          // memory path -- one fill outstanding instead of four while that lasts (MI355X_MICROARCH.md "gather-pass")
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (i >= 3) flag_landed(i - 3);
+          if (i >= 2) flag_landed(i - 2);
+          if (i >= 1) flag_landed(i - 1);
+          flag_landed(i);
+        } else if (i >= 3) {
           asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
           flag_landed(i - 3);
         }
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   // from 4 - 16 producers, the others finish around the same time -- the tags of the full sweep decide.
   auto gather = [&](auto nch, gu64* g, int chunks, unsigned tag, lds_u* stage, auto&& idle) {
     constexpr int NCH = decltype(nch)::value;
+    if (lane == 0) __hip_atomic_fetch_add((lds_u*)(fl + F_SWEEP), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (cw < chunks && a.hint) {
       gu64* hp = g + (size_t)cw * 1024 + (size_t)((cu + 5 * cw) & 15) * 64 + lane;
       unsigned spins = 0;
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
     }
     ++gath_no;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((lds_u*)(fl + F_SWEEP), 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0) __hip_atomic_fetch_add((lds_u*)(fl + F_GATH), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (ok && !lds_wait_ge(fl + F_GATH, 3u * gath_no, deadline, dead)) ok = false;
     asm volatile("" ::: "memory");
@@ -763,6 +773,7 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
   const char* edr = getenv("UMB_CHAIN_TEST_DROP_CU");
   a.drop_cu = edr ? atoi(edr) : -1;
   static const int hint_on = getenv("UMB_CHAIN_HINT") ? atoi(getenv("UMB_CHAIN_HINT")) : 1;
+  static const int thin_on = getenv("UMB_CHAIN_THIN") ? atoi(getenv("UMB_CHAIN_THIN")) : 1;
   a.hint = hint_on;
 #ifdef UMB_CHAIN_TRACE
   const char* etr = getenv("UMB_CHAIN_TRACE_PTR");
@@ -782,7 +793,8 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
       attr_done = true;                                                                                                \
     }                                                                                                                  \
     hipLaunchKernelGGL((draft_chain_kernel<P, TTV>), dim3(256), dim3(256), lds, st, a.w_o, a.w_gu, a.w_down, a.w_qkv,  \
-                       a.R, off_flags, (c->front ? 1 : 0) | (c->tail ? 2 : 0), slots, (unsigned)a.timeout_ticks, a);      \
+                       a.R, off_flags, (c->front ? 1 : 0) | (c->tail ? 2 : 0) | (thin_on ? 4 : 0), slots,               \
+                       (unsigned)a.timeout_ticks, a);                                                                 \
   } while (0)
   DISPATCH_DTYPE(dtype, {
     if (T == 1) CH_GO(1);
