@@ -81,7 +81,7 @@ template <int TT> __device__ __forceinline__ float ch_fold(const float (&v)[TT])
 
 enum { CH_SLOT = 16384, CH_MAXRING = 8 };
 // flag words (u32 index into the flag area)
-enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_SWEEP = 33 /* consumers inside a sweep */, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41,
+enum { F_LANDED = 0, F_FREED = 16, F_GATH = 32, F_SWEEP = 33 /* consumers inside a sweep */, F_GO = 34, F_PAIR = 36, F_SQCNT = 40, F_DEAD = 41,
        F_SQ = 48 /* float [8][4] */, F_HV = 80 /* u32 [8][4] */, F_WORDS = 128 };
 
 struct ChainArgs {
@@ -95,7 +95,7 @@ struct ChainArgs {
   float eps;
   unsigned off_sth, off_sta;
   long long timeout_ticks;
-  int hint;                           // 1: poll one 512-byte piece before the full sweeps (UMB_CHAIN_HINT=0: experiments)
+  int hint;                           // sentinel poll before the full sweeps: 2 one wave per CU (default), 1 every consumer, 0 none
   int drop_cu;                        // test hook (UMB_CHAIN_TEST_DROP_CU): this workgroup withholds its o-projection granules
   unsigned long long* trace;          // UMB_CHAIN_TRACE builds only
 };
@@ -355,12 +355,22 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   auto gather = [&](auto nch, gu64* g, int chunks, unsigned tag, lds_u* stage, auto&& idle) {
     constexpr int NCH = decltype(nch)::value;
     if (lane == 0) __hip_atomic_fetch_add((lds_u*)(fl + F_SWEEP), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (cw < chunks && a.hint) {
-      gu64* hp = g + (size_t)cw * 1024 + (size_t)((cu + 5 * cw) & 15) * 64 + lane;
+    if (a.hint) {
+      // hint 1: every consumer polls a piece of its own first chunk; hint 2: ONE wave of the CU polls (consumer 0), the other
+      // two wait on an LDS word.  One loop, one idle() site (a second copy of the preload code cost 441 spilled registers)
+      const bool poller = a.hint == 2 ? cw == 0 : cw < chunks;
+      const bool waiter = a.hint == 2 && cw != 0;
+      gu64* hp = g + (size_t)(a.hint == 2 ? 0 : cw) * 1024 + (size_t)((cu + 5 * cw) & 15) * 64 + lane;
       unsigned spins = 0;
-      for (;;) {
-        const unsigned long long gv = __hip_atomic_load(hp, RLX_AGENT);
-        if (__all((unsigned)(gv >> 32) == tag) || !ok) break;
+      while (poller || waiter) {
+        bool done;
+        if (poller) {
+          const unsigned long long gv = __hip_atomic_load(hp, RLX_AGENT);
+          done = __all((unsigned)(gv >> 32) == tag);
+        } else {
+          done = __builtin_amdgcn_readfirstlane(fl[F_GO]) >= gath_no + 1;
+        }
+        if (done || !ok) break;
         idle();
         __builtin_amdgcn_s_sleep(4);
         if ((++spins & 127u) == 0) {
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
           else if (__builtin_amdgcn_readfirstlane((int)((long long)wall_clock64() > deadline))) { *dead = 1; ok = false; }
         }
       }
+      if (a.hint == 2 && cw == 0 && lane == 0) fl[F_GO] = gath_no + 1;
     }
     unsigned pend = 0;                                 // bit j: chunk cw + 3 j still incomplete
 #pragma unroll
@@ -772,7 +783,7 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
   a.timeout_ticks = (etm ? atoll(etm) : 20ll) * 100000ll;
   const char* edr = getenv("UMB_CHAIN_TEST_DROP_CU");
   a.drop_cu = edr ? atoi(edr) : -1;
-  static const int hint_on = getenv("UMB_CHAIN_HINT") ? atoi(getenv("UMB_CHAIN_HINT")) : 1;
+  static const int hint_on = getenv("UMB_CHAIN_HINT") ? atoi(getenv("UMB_CHAIN_HINT")) : 2;
   static const int thin_on = getenv("UMB_CHAIN_THIN") ? atoi(getenv("UMB_CHAIN_THIN")) : 1;
   a.hint = hint_on;
 #ifdef UMB_CHAIN_TRACE
