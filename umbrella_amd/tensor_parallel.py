@@ -190,7 +190,7 @@ class PeerExchange:
     kernel launches per all-reduce in the rank's own stream (umb_tp_publish / umb_tp_reduce_residual_norm)."""
     FLAG_BYTES = 256
 
-    def __init__(self, comm: "TPComm", cap_floats: int, device):
+    def __init__(self, comm: "TPComm", cap_floats: int, device, require_fine_grained: bool = False):
         import ctypes as C
         dist = comm.dist
         lib = _lib.load()
@@ -231,10 +231,19 @@ class PeerExchange:
             elif err is None:
                 err = RuntimeError("a peer rank could not allocate its exchange buffer")
             oks = [None] * self.world
-            dist.all_gather_object(oks, err is None, group=comm.group)
-            if not all(oks):
+            pr = torch.cuda.get_device_properties(torch.device(device))
+            where = (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            dist.all_gather_object(oks, (err is None, self.fine_grained, where), group=comm.group)
+            if not all(o[0] for o in oks):
                 self.close()
                 raise PeerExchangeUnavailable(str(err) if err is not None else "a peer rank could not map the exchange buffers")
+            # Ordinary (coarse-grained) device memory read ACROSS devices has never run on hardware (every box of this pool has one
+            # GPU): in "auto" the group takes the collective hook there.  Ranks sharing one device (the tests) read through one
+            # L2 and keep the path; UMB_TP_ALLREDUCE=peer keeps it anywhere.  Decided from gathered facts: the same on every rank.
+            if require_fine_grained and len({o[2] for o in oks}) > 1 and not all(o[1] for o in oks):
+                self.close()
+                raise PeerExchangeUnavailable("exchange buffers in ordinary device memory on more than one device: "
+                                              "not validated, UMB_TP_ALLREDUCE=peer forces it")
         self.words = torch.zeros(64, dtype=torch.int32, device=device)       # epoch | arrive | status, 64 bytes apart
         d = _lib.UmbTPPeer()
         d.rank, d.world, d.cap, d.spin_limit = self.rank, self.world, self.cap, int(os.environ.get("UMB_TP_SPIN", "0"))
@@ -305,7 +314,7 @@ class TensorParallelLlama:
         mode = os.environ.get("UMB_TP_ALLREDUCE", "auto")
         if comm.live and comm.world > 1 and mode != "hook" and str(self.device).startswith("cuda"):
             try:
-                self.peer = PeerExchange(comm, self.PEER_MAX_ROWS * cfg.hidden_size, self.device)
+                self.peer = PeerExchange(comm, self.PEER_MAX_ROWS * cfg.hidden_size, self.device, require_fine_grained=(mode == "auto"))
                 self._peer_ptr = C.pointer(self.peer.desc)       # kept: reading `tp.peer` back yields a VIEW of the field, not a copy
                 tp.peer = self._peer_ptr
                 tp.peer_max_floats = self.PEER_MAX_ROWS * cfg.hidden_size
