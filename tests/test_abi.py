@@ -185,7 +185,7 @@ def test_chain_kernels_neither_spill_nor_use_scratch(tmp_path):
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
-        if not (name and "draft_chain_kernel" in name):
+        if not (name and ("draft_chain_kernel" in name or "draft_head_kernel" in name)):
             continue
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m:
@@ -194,4 +194,4 @@ def test_chain_kernels_neither_spill_nor_use_scratch(tmp_path):
         m = re.search(r"VGPRs Spill: (\d+)", line)
         if m:
             assert int(m.group(1)) == 0, (name, "spilled VGPRs", int(m.group(1)))
-    assert seen == 6                      # 2 dtypes x 3 row counts
+    assert seen == 6 + 8                  # chain: 2 dtypes x 3 row counts; streamed lm_head: 2 dtypes x 4

@@ -141,3 +141,57 @@ def test_chain_rejects_what_it_does_not_cover(dev):
 def C_byref(x):
     import ctypes as C
     return C.byref(x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+@pytest.mark.parametrize("V", [128256, 8208])
+def test_head_stream_equals_fp32_arithmetic_and_the_mfma_head(dev, dtype, rows, V):
+    """umb_head_stream (the <= 4-row lm_head on the streaming engine): logits = round(1/rms * hw W^T) against fp32 torch on the same
+    16-bit operands (one rounding of an fp32-accumulated sum: a unit in the last place of the model dtype, plus the dot product's
+    fp32 summation-order noise), and against the MFMA kernel the other forwards use (umb_gemm_fused, epilogue 1) to the same
+    bound.  V = 8208: 2052 slots over 256 workgroups (8 or 9 each, uneven); 128256: the Llama vocabulary (125 / 126)."""
+    import ctypes as C
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import PackedLinear
+    lib = _lib.load()
+    assert lib.umb_head_stream_ok(rows, V, 2048) == 1
+    assert lib.umb_head_stream_ok(5, V, 2048) == 0 and lib.umb_head_stream_ok(rows, V, 4096) == 0 and lib.umb_head_stream_ok(rows, V + 2, 2048) == 0
+    H, G, stride = 2048, 32, 256
+    g = torch.Generator(device=dev).manual_seed(V + rows)
+    W = (torch.randn(V, H, device=dev, generator=g) * 0.03).to(dtype)
+    x = torch.randn(rows, H, device=dev, generator=g).to(dtype)
+    ssq = torch.zeros(rows, stride, device=dev)
+    ssq[:, :G] = torch.rand(rows, G, device=dev, generator=g) * 40 + 20
+    eps = 1e-5
+    inv = torch.rsqrt(ssq[:, :G].double().sum(1) / H + eps).float()
+    ref = ((x.float() @ W.float().T) * inv[:, None])
+    out = torch.full((rows, V), float("nan"), device=dev)
+    _lib.call("umb_head_stream", out, x, ssq, stride, G, eps, W, rows, V, H, _lib.dtype_code(dtype))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, out.to(dtype).float())                           # every logit is a value of the model dtype
+    tol = torch.finfo(dtype).eps * ref.abs().clamp_min(ref.abs().max() * 1e-2) + 1e-6
+    assert ((out - ref).abs() <= tol).all(), float(((out - ref).abs() / tol).max())
+    lin = PackedLinear.from_dense(W, force_s1=True)
+    fx = _lib.UmbGemmFused()
+    fx.ssq_in, fx.ssq_groups, fx.pad0 = ssq.data_ptr(), G, stride
+    fx.ssq_dim, fx.eps = float(H), eps
+    out2 = torch.empty(rows, V, device=dev)
+    _lib.call("umb_gemm_fused", out2, x, H, lin.w, lin.meta, rows, V, H, 0, 1, lin.Rtb, 1, fx, _lib.dtype_code(dtype))
+    torch.cuda.synchronize()
+    assert ((out - out2).abs() <= tol).all()
+
+
+def test_draft_forward_takes_the_streamed_head(dev):
+    """a tied 1B-class draft publishes its embedding table as the head's row copy and the <= 4-row forwards use it: switching
+    the streamed head off (UMB_NO_HEAD_STREAM is read once per process, so through the struct field here) changes logits only
+    within rounding, and the arg-max of every row stays"""
+    m = _draft(dev, torch.float16, 2, True)
+    assert m._m.lm_head.w_rows == m.embed_tokens.data_ptr()
+    la = _step(m, dev, 3)[0]
+    m._m.lm_head.w_rows = 0
+    lb = _step(m, dev, 3)[0]
+    assert not torch.equal(la, lb)                                            # another kernel, another summation order
+    assert (la - lb).abs().max() <= 4 * torch.finfo(torch.float16).eps * lb.abs().max()
+    assert torch.equal(la.argmax(-1), lb.argmax(-1))

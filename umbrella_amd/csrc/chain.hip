@@ -704,6 +704,135 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
   if (!ok && lane == 0 && a.status) __hip_atomic_fetch_or(a.status, 0xDEAD0000u | (unsigned)(cu & 0xffff), RLX_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lm_head of the <= 4-row forwards on the same engine (round 5): logits[r][v] = round(1/rms_r * sum_k hw[r][k] W[v][k]) for the
+// tied embedding table W [V][2048] (row-major as it is: no second copy).  Reference: `self.lm_head(hidden_states)` behind the final
+// norm, umbrella/models/llama.py:130-133.  The MFMA kernel walks its 1002 blocks in two rounds per CU and pays the ramp of a
+// launch in each (525 MB in 96 us = 5.4 TB/s; the same kernel reads the 70B's 2.1 GB head at 6.4); here ONE workgroup per CU
+// streams its 125 / 126 four-row slots through the LDS ring without a break -- no hand-off between CUs, so nothing can stall
+// but the loader / consumer ring inside a workgroup.  Operand rows and 1/rms as in the chain's tail-only launch.
+template <typename P, int TT>
+__global__ __launch_bounds__(256) void draft_head_kernel(const char* w, int R, unsigned off_flags, int nslots_total, unsigned timeout_ticks,
+                                                         const u16* __restrict__ hw, const float* __restrict__ ssq, int ssq_stride,
+                                                         int ssq_groups, float eps, float* __restrict__ logits, int T, int V) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = 2048;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cu = blockIdx.x, ncu = gridDim.x;
+  lds_vu* fl = (lds_vu*)((lds_char*)smem + off_flags);
+  if (threadIdx.x < F_WORDS) fl[threadIdx.x] = 0;
+  __syncthreads();
+  const long long deadline = (long long)wall_clock64() + (long long)timeout_ticks;
+  lds_vu* dead = fl + F_DEAD;
+  // slots of this CU: the first (total % ncu) CUs take one more
+  const int base = nslots_total / ncu, rem = nslots_total - base * ncu;
+  const int n = base + (cu < rem ? 1 : 0);
+  const int first = cu * base + min(cu, rem);
+  if (wv == 0) {
+    // ---- loader: the chain's (four pieces per M0 setting, up to four slots in flight, slot i - 3 published after slot i is issued)
+    const unsigned ring0 = (unsigned)(size_t)(lds_char*)smem;
+    const unsigned voff = (unsigned)lane * 16u;
+    const char* src = w + (size_t)first * CH_SLOT;
+    int sk = cu % n, p = 0;
+    auto flag_landed = [&](int slot_i) { if (lane == 0) fl[F_LANDED + slot_i % R] = (unsigned)slot_i + 1u; };
+    for (int i = 0; i < n; ++i) {
+      if (i >= R && __builtin_amdgcn_readfirstlane(fl[F_FREED + p]) < (unsigned)(i - R + 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i >= 3) flag_landed(i - 3);
+        if (i >= 2) flag_landed(i - 2);
+        if (i >= 1) flag_landed(i - 1);
+        if (!lds_wait_ge(fl + F_FREED + p, (unsigned)(i - R + 1), deadline, dead)) return;
+      }
+      const unsigned dst = ring0 + (unsigned)p * CH_SLOT;
+      const char* sp = src + (size_t)sk * CH_SLOT;
+      if (++sk == n) sk = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sp + j * 4096), "s"(dst + j * 4096) : "memory");
+      }
+      if (i >= 3) {
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        flag_landed(i - 3);
+      }
+      if (++p == R) p = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    if (n >= 3) flag_landed(n - 3);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (n >= 2) flag_landed(n - 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n >= 1) flag_landed(n - 1);
+    return;
+  }
+  // ---- consumers
+  const int cw = wv - 1;
+  const int tl = lane >> 4;
+  const bool fin = (lane & 15) == 0 && tl < T;
+  const int OOB = (int)0x80000000;
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(hw), 0, (unsigned)(T * H * 2), 0x00020000);
+  u32x4 x[TT][4];                                      // lane l holds k = 512 kc + 8 l .. + 7 of every operand row
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) x[t][kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, (t * H + kc * 512 + lane * 8) * 2, 0, 0);
+  const auto rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ssq), 0, (unsigned)((T - 1) * ssq_stride + ssq_groups) * 4u, 0x00020000);
+  float ssum[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) {
+    float sq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gq = lane + 64 * q;
+      sq[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsq, (t < T && gq < ssq_groups) ? (t * ssq_stride + gq) * 4 : OOB, 0, 0));
+    }
+    ssum[t] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
+  }
+  const float inv = rsqrtf(ch_fold<TT>(ssum) / (float)H + eps);      // row t of the wave: token t
+  bool ok = true;
+  for (int k = cw; k < n; k += 3) {
+    const int sa = (k + cu) % n;                       // the loader's slot order
+    const int pos = k % R;
+    if (ok && !lds_wait_ge(fl + F_LANDED + pos, (unsigned)k + 1u, deadline, dead)) ok = false;
+    asm volatile("" ::: "memory");
+    const lds_char* sp = (const lds_char*)smem + (size_t)pos * CH_SLOT;
+    u32x4 wr[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) wr[r][kc] = *(const __attribute__((address_space(3))) u32x4*)(sp + r * 4096 + kc * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) fl[F_FREED + pos] = (unsigned)k + 1u;
+    float part[4][TT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) part[r][t] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < TT; ++t) part[r][t] = ch_dot2<P>(wr[r][kc][e], x[t][kc][e], part[r][t]);
+    float acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = ch_fold<TT>(part[r]);
+    if (fin) {
+      f32x4 o = {rnd_prod<P>(acc[0], inv), rnd_prod<P>(acc[1], inv), rnd_prod<P>(acc[2], inv), rnd_prod<P>(acc[3], inv)};
+      *reinterpret_cast<f32x4*>(logits + (long)tl * V + (long)(first + sa) * 4) = o;
+    }
+  }
+}
+
 // ---- host side
 static int chain_ring(int T) {
   // 160 KiB per CU: staging [T][H] (4 KiB per row) + [T][I] (16 KiB per row) + flags, the rest is the ring
@@ -813,6 +942,46 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
     else CH_GO(3);
   })
 #undef CH_GO
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
+// lm_head of a <= 4-row forward on the streaming engine (see draft_head_kernel).  w_rows: the head's weights as plain row-major
+// [V][2048] rows (a tied model's embedding table as it is).  x: [rows][2048] = h * final-norm weight, ssq: the producer's sums of
+// squares ([rows][ssq_stride], `groups` valid), logits: fp32 [rows][V].
+extern "C" int umb_head_stream_ok(int rows, int V, int H) {
+  static const bool off = getenv("UMB_NO_HEAD_STREAM") != nullptr;
+  if (off || rows < 1 || rows > 4 || H != 2048 || V % 4 || V < 4 * 256 * 8) return 0;
+  static int ncu = -1;
+  if (ncu < 0) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 0;
+  }
+  return ncu == 256;
+}
+extern "C" int umb_head_stream(float* logits, const void* x, const float* ssq, int ssq_stride, int groups, float eps,
+                               const void* w_rows, int rows, int V, int H, int dtype, hipStream_t st) {
+  if (!umb_head_stream_ok(rows, V, H) || !logits || !x || !ssq || !w_rows || groups < 1 || groups > 256 || groups > ssq_stride) return UMB_EINVAL;
+  const int R = 8;                                      // ring: 8 x 16 KiB; the operand rows live in registers
+  const unsigned off_flags = (unsigned)R * CH_SLOT;
+  const unsigned lds = off_flags + F_WORDS * 4u;
+  static const unsigned ticks = 100000u * (unsigned)(getenv("UMB_CHAIN_TIMEOUT_MS") ? atoi(getenv("UMB_CHAIN_TIMEOUT_MS")) : 20);
+#define UMB_HEAD_(PT, TTV)                                                                                                       \
+  do {                                                                                                                           \
+    static bool once = false;                                                                                                    \
+    if (!once) {                                                                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&draft_head_kernel<PT, TTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess) return UMB_EHIP;                                                          \
+      once = true;                                                                                                               \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((draft_head_kernel<PT, TTV>), dim3(256), dim3(256), lds, st, (const char*)w_rows, R, off_flags, V / 4, ticks, \
+                       (const u16*)x, ssq, ssq_stride, groups, eps, logits, rows, V);                                            \
+  } while (0)
+  DISPATCH_DTYPE(dtype, {
+    if (rows == 1) UMB_HEAD_(P, 1); else if (rows == 2) UMB_HEAD_(P, 2); else if (rows == 3) UMB_HEAD_(P, 3); else UMB_HEAD_(P, 4);
+  })
+#undef UMB_HEAD_
   UMB_LAUNCH_CHECK();
   return UMB_OK;
 }

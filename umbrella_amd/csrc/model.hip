@@ -388,6 +388,10 @@ static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
   if (s->head_from >= s->T) return UMB_OK;
   const int rows = s->T - s->head_from;
   const char* x = (const char*)ws->hw + (size_t)s->head_from * m->H * 2;
+  // the head's rows as a plain row-major table (a tied model's embedding table): the streaming engine of chain.hip
+  if (m->lm_head.w_rows && umb_head_stream_ok(rows, m->lm_head.N, m->H))
+    return umb_head_stream(ws->logits, x, ws->ssq + (size_t)s->head_from * ws->ssq_stride, ws->ssq_stride, groups, m->eps,
+                           m->lm_head.w_rows, rows, m->lm_head.N, m->H, m->dtype, st);
   UmbGemmFused fh = {};
   fh.ssq_in = ws->ssq + (size_t)s->head_from * ws->ssq_stride; fh.ssq_groups = groups; fh.pad0 = ws->ssq_stride;
   fh.ssq_dim = (float)m->H; fh.eps = m->eps;

@@ -348,6 +348,10 @@ class Llama(LLMBase):
             assert head_w.shape == (V, H), (tuple(head_w.shape), V, H)
             self.lm_head = PackedLinear.from_dense(head_w, force_s1=True)
             assert self.lm_head.N == V
+            # a tied head's rows exist already as a plain row-major table: the <= 4-row forwards of a DRAFT stream them through
+            # the engine of csrc/chain.hip (umb_head_stream; published by use_gemv like the layers' row copies)
+            if c.tie_word_embeddings and self.embed_tokens is not None and tuple(self.embed_tokens.shape) == (V, H):
+                self.lm_head.w_rows = self.embed_tokens
             del head_w
             self.norm_weight = fetch("model.norm.weight", (H,), "norm").to(dt).contiguous()
         else:
@@ -477,6 +481,10 @@ class Llama(LLMBase):
                 rows = getattr(ln, "w_rows", None)
                 streamed = self.host_slabs[i] is not None
                 getattr(self._layer_structs[i], key).w_rows = rows.data_ptr() if (on and rows is not None and not streamed) else 0
+        if getattr(self, "lm_head", None) is not None:
+            self.lm_head.gemv_on = bool(on)
+            rows = getattr(self.lm_head, "w_rows", None)
+            self._m.lm_head.w_rows = rows.data_ptr() if (on and rows is not None and self._tp is None) else 0
         self.gemv = bool(on)
         self._chain_setup()
 
