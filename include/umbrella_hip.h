@@ -158,15 +158,16 @@ size_t umb_chain_xchg_bytes(int Tmax, int H, int I);
 int umb_chain_xchg_init(void* xchg, int Tmax, int H, int I, umb_stream_t stream);
 int umb_chain_status(const void* xchg, int Tmax, int H, int I, uint32_t* status_out, umb_stream_t stream);
 int umb_draft_chain(const UmbChain* c, int dtype, umb_stream_t stream);
-/* lm_head of a <= 4-row forward of the same models on the same engine (`self.lm_head(hidden_states)` behind the final norm,
+/* lm_head of a <= 8-row forward of the same models on the same engine (`self.lm_head(hidden_states)` behind the final norm,
  * umbrella/models/llama.py:130-133): ONE workgroup per CU streams its share of the head's rows -- plain row-major [V][2048], a tied
  * model's embedding table as it is -- through an LDS ring and multiplies from there; no hand-off between workgroups.  x: [rows][2048]
  * = h * final-norm weight; ssq: the producer's sums of squares ([rows][ssq_stride], `groups` valid: 1/rms is applied to the outputs);
- * logits: fp32 [rows][V], every value rounded to the model dtype as F.linear returns it.  umb_head_stream_ok: rows <= 4, H == 2048,
+ * logits: fp32 [rows][V], every value rounded to the model dtype as F.linear returns it.  x_fm_tt: 0 = x row-major, > 0 = x in FM
+ * order with that many token tiles (the low-latency schedule's activations).  umb_head_stream_ok: rows <= 8, H == 2048,
  * V % 4 == 0, a 256-CU device (UMB_NO_HEAD_STREAM answers 0: the MFMA kernel of umb_gemm takes the head). */
 int umb_head_stream_ok(int rows, int V, int H);
 int umb_head_stream(float* logits, const void* x, const float* ssq, int ssq_stride, int groups, float eps, const void* w_rows,
-                    int rows, int V, int H, int dtype, umb_stream_t stream);
+                    int rows, int V, int H, int x_fm_tt, int dtype, umb_stream_t stream);
 
 /* (R n-tiles per wave, WN row groups x WK K-slices = NW waves per block) for a [N][K] linear: shape-only, so a
  * token's result never depends on its batch mates; epi 4 writes N / 16 / R sums of squares per token. */

@@ -15,7 +15,7 @@ cp gpurun_out/r05_pmc_gemm70b_traffic.json "$out/" 2>/dev/null
 f=$(find "$out/bench_stats" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$out/r05_bench70b_kernel_stats.csv"
 t=$(find "$out/bench_stats" -name "*kernel_trace.csv" | head -1)
-[ -n "$t" ] && python scripts/trace_by_shape.py "$t" "$out/r05_bench70b_kernels_by_shape.csv" skinny_gemm ll_gemm gv_kernel draft_chain reduce_ tree_attn topk accept kv_compact embed rmsnorm argmax
+[ -n "$t" ] && python scripts/trace_by_shape.py "$t" "$out/r05_bench70b_kernels_by_shape.csv" skinny_gemm ll_gemm gv_kernel draft_chain draft_head reduce_ tree_attn topk accept kv_compact embed rmsnorm argmax
 find "$out/bench_stats" -name "*kernel_trace.csv" -delete
 # 3. per-kernel times of the graph-replayed 1B forward at 3 rows: persistent chain (default) and the five GEMV launches
 SCHEDS=auto T1B=3 bash scripts/prof_fwd.sh fwd1b > "$out/prof_fwd1b.log" 2>&1

@@ -38,6 +38,7 @@ ALG = {
         ("gv_kernel<F16, 2, 1, 3>", 256): ("qkv fp16 N3072 K2048", dense_bytes(3072, 2048)),
         ("gv_kernel<F16, 1, 1, 4>", 256): ("o fp16 N2048 K2048", dense_bytes(2048, 2048)),
         ("skinny_gemm_kernel", 1002): ("lm_head fp16 N128256 K2048", dense_bytes(128256, 2048)),
+        ("draft_head_kernel", 256): ("engine lm_head fp16 N128256 K2048 (tied table, row-major)", dense_bytes(128256, 2048)),
         ("draft_chain_kernel", 256): ("engine chain o + gate/up + down + qkv (1 launch)", dense_bytes(2048, 2048) + dense_bytes(16384, 2048) + dense_bytes(2048, 8192) + dense_bytes(3072, 2048)),
     },
     "fwd8bawq": {  # Llama-3.1-8B AWQ: H 4096, I 14336, q/k/v N 6144
@@ -99,7 +100,7 @@ def alg_of(name, blocks):
     return ("", None)
 
 
-keep = ("skinny_gemm", "gv_kernel", "ll_gemm", "reduce_", "tree_attn", "embed", "rmsnorm", "draft_chain", "topk", "verify_gemm")
+keep = ("skinny_gemm", "gv_kernel", "ll_gemm", "reduce_", "tree_attn", "embed", "rmsnorm", "draft_chain", "draft_head", "topk", "verify_gemm")
 rows = []
 for k, v in dur.items():
     name, blocks = k

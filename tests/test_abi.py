@@ -194,4 +194,4 @@ def test_chain_kernels_neither_spill_nor_use_scratch(tmp_path):
         m = re.search(r"VGPRs Spill: (\d+)", line)
         if m:
             assert int(m.group(1)) == 0, (name, "spilled VGPRs", int(m.group(1)))
-    assert seen == 6 + 8                  # chain: 2 dtypes x 3 row counts; streamed lm_head: 2 dtypes x 4
+    assert seen == 6 + 16                 # chain: 2 dtypes x 3 row counts; streamed lm_head: 2 dtypes x 8

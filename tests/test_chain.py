@@ -144,10 +144,11 @@ def C_byref(x):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+@pytest.mark.parametrize("rows,fm", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 1), (6, 1), (7, 0), (8, 1)])
 @pytest.mark.parametrize("V", [128256, 8208])
-def test_head_stream_equals_fp32_arithmetic_and_the_mfma_head(dev, dtype, rows, V):
-    """umb_head_stream (the <= 4-row lm_head on the streaming engine): logits = round(1/rms * hw W^T) against fp32 torch on the same
+def test_head_stream_equals_fp32_arithmetic_and_the_mfma_head(dev, dtype, rows, fm, V):
+    """umb_head_stream (the <= 8-row lm_head on the streaming engine; fm: operand rows handed over in FM order as the low-latency
+    schedule's 5 ... 8-row levels do): logits = round(1/rms * hw W^T) against fp32 torch on the same
     16-bit operands (one rounding of an fp32-accumulated sum: a unit in the last place of the model dtype, plus the dot product's
     fp32 summation-order noise), and against the MFMA kernel the other forwards use (umb_gemm_fused, epilogue 1) to the same
     bound.  V = 8208: 2052 slots over 256 workgroups (8 or 9 each, uneven); 128256: the Llama vocabulary (125 / 126)."""
@@ -156,7 +157,7 @@ def test_head_stream_equals_fp32_arithmetic_and_the_mfma_head(dev, dtype, rows, 
     from umbrella_amd.models.llama import PackedLinear
     lib = _lib.load()
     assert lib.umb_head_stream_ok(rows, V, 2048) == 1
-    assert lib.umb_head_stream_ok(5, V, 2048) == 0 and lib.umb_head_stream_ok(rows, V, 4096) == 0 and lib.umb_head_stream_ok(rows, V + 2, 2048) == 0
+    assert lib.umb_head_stream_ok(9, V, 2048) == 0 and lib.umb_head_stream_ok(rows, V, 4096) == 0 and lib.umb_head_stream_ok(rows, V + 2, 2048) == 0
     H, G, stride = 2048, 32, 256
     g = torch.Generator(device=dev).manual_seed(V + rows)
     W = (torch.randn(V, H, device=dev, generator=g) * 0.03).to(dtype)
@@ -167,7 +168,11 @@ def test_head_stream_equals_fp32_arithmetic_and_the_mfma_head(dev, dtype, rows, 
     inv = torch.rsqrt(ssq[:, :G].double().sum(1) / H + eps).float()
     ref = ((x.float() @ W.float().T) * inv[:, None])
     out = torch.full((rows, V), float("nan"), device=dev)
-    _lib.call("umb_head_stream", out, x, ssq, stride, G, eps, W, rows, V, H, _lib.dtype_code(dtype))
+    xin = x
+    if fm:
+        xin = torch.zeros(16 * H, dtype=dtype, device=dev)
+        _lib.call("umb_to_fm", xin, x, rows, H, _lib.dtype_code(dtype))
+    _lib.call("umb_head_stream", out, xin, ssq, stride, G, eps, W, rows, V, H, 1 if fm else 0, _lib.dtype_code(dtype))
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert torch.equal(out, out.to(dtype).float())                           # every logit is a value of the model dtype

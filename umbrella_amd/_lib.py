@@ -137,7 +137,7 @@ SIGNATURES = {
     "umb_chain_status": [_P, _I, _I, _I, C.POINTER(C.c_uint32), _P],
     "umb_draft_chain": [C.POINTER(UmbChain), _I, _P],
     "umb_head_stream_ok": [_I, _I, _I],
-    "umb_head_stream": [_P, _P, _P, _I, _I, _F, _P, _I, _I, _I, _I, _P],
+    "umb_head_stream": [_P, _P, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _P],
     "umb_ll_plan": [_I, _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "umb_ll_token_tiles": [_I],
     "umb_to_fm": [_P, _P, _I, _I, _I, _P],

@@ -714,7 +714,10 @@ __global__ __launch_bounds__(256) void draft_chain_kernel(const char* w_o, const
 template <typename P, int TT>
 __global__ __launch_bounds__(256) void draft_head_kernel(const char* w, int R, unsigned off_flags, int nslots_total, unsigned timeout_ticks,
                                                          const u16* __restrict__ hw, const float* __restrict__ ssq, int ssq_stride,
-                                                         int ssq_groups, float eps, float* __restrict__ logits, int T, int V) {
+                                                         int ssq_groups, float eps, float* __restrict__ logits, int T, int V,
+                                                         int x_fm_tt) {
+  // TT <= 4: token t's sums fold into row t of a wave (ch_fold); TT = 5 .. 8: two folds, tokens 0-3 and 4-7, lane 16 t finishes
+  // tokens t and 4 + t.  x_fm_tt > 0: the operand rows are in FM order with that many token tiles (the low-latency schedule's hw).
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = 2048;
   const int lane = threadIdx.x & 63;
@@ -775,14 +778,19 @@ __global__ __launch_bounds__(256) void draft_head_kernel(const char* w, int R, u
   // ---- consumers
   const int cw = wv - 1;
   const int tl = lane >> 4;
-  const bool fin = (lane & 15) == 0 && tl < T;
+  constexpr int TA = TT < 4 ? TT : 4, TB = TT > 4 ? TT - 4 : 1;
+  const bool finA = (lane & 15) == 0 && tl < T, finB = TT > 4 && (lane & 15) == 0 && 4 + tl < T;
   const int OOB = (int)0x80000000;
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(hw), 0, (unsigned)(T * H * 2), 0x00020000);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(hw), 0, (unsigned)((x_fm_tt ? x_fm_tt * 16 : T) * H * 2), 0x00020000);
   u32x4 x[TT][4];                                      // lane l holds k = 512 kc + 8 l .. + 7 of every operand row
 #pragma unroll
   for (int t = 0; t < TT; ++t)
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) x[t][kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, (t * H + kc * 512 + lane * 8) * 2, 0, 0);
+    for (int kc = 0; kc < 4; ++kc) {
+      const int f = kc * 512 + lane * 8;               // FM: 8 consecutive features of one token are one 16-byte piece (common.h fm_off)
+      const int off = x_fm_tt ? ((((f >> 5) * x_fm_tt + (t >> 4)) * 64 + ((f >> 3) & 3) * 16 + (t & 15)) << 3) : t * H + f;
+      x[t][kc] = __builtin_amdgcn_raw_buffer_load_b128(rx, t < T ? off * 2 : OOB, 0, 0);
+    }
   const auto rsq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ssq), 0, (unsigned)((T - 1) * ssq_stride + ssq_groups) * 4u, 0x00020000);
   float ssum[TT];
 #pragma unroll
@@ -795,7 +803,13 @@ __global__ __launch_bounds__(256) void draft_head_kernel(const char* w, int R, u
     }
     ssum[t] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
   }
-  const float inv = rsqrtf(ch_fold<TT>(ssum) / (float)H + eps);      // row t of the wave: token t
+  float sA[TA], sB[TB];
+#pragma unroll
+  for (int t = 0; t < TA; ++t) sA[t] = ssum[t];
+#pragma unroll
+  for (int t = 0; t < TB; ++t) sB[t] = TT > 4 ? ssum[4 + t] : 0.f;
+  const float invA = rsqrtf(ch_fold<TA>(sA) / (float)H + eps);       // row t of the wave: token t
+  const float invB = TT > 4 ? rsqrtf(ch_fold<TB>(sB) / (float)H + eps) : 1.f;   // ... token 4 + t
   bool ok = true;
   for (int k = cw; k < n; k += 3) {
     const int sa = (k + cu) % n;                       // the loader's slot order
@@ -823,12 +837,24 @@ __global__ __launch_bounds__(256) void draft_head_kernel(const char* w, int R, u
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int t = 0; t < TT; ++t) part[r][t] = ch_dot2<P>(wr[r][kc][e], x[t][kc][e], part[r][t]);
-    float acc[4];
+    float accA[4], accB[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = ch_fold<TT>(part[r]);
-    if (fin) {
-      f32x4 o = {rnd_prod<P>(acc[0], inv), rnd_prod<P>(acc[1], inv), rnd_prod<P>(acc[2], inv), rnd_prod<P>(acc[3], inv)};
+    for (int r = 0; r < 4; ++r) {
+      float pa[TA], pb[TB];
+#pragma unroll
+      for (int t = 0; t < TA; ++t) pa[t] = part[r][t];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) pb[t] = TT > 4 ? part[r][4 + t] : 0.f;
+      accA[r] = ch_fold<TA>(pa);
+      accB[r] = TT > 4 ? ch_fold<TB>(pb) : 0.f;
+    }
+    if (finA) {
+      f32x4 o = {rnd_prod<P>(accA[0], invA), rnd_prod<P>(accA[1], invA), rnd_prod<P>(accA[2], invA), rnd_prod<P>(accA[3], invA)};
       *reinterpret_cast<f32x4*>(logits + (long)tl * V + (long)(first + sa) * 4) = o;
+    }
+    if (finB) {
+      f32x4 o = {rnd_prod<P>(accB[0], invB), rnd_prod<P>(accB[1], invB), rnd_prod<P>(accB[2], invB), rnd_prod<P>(accB[3], invB)};
+      *reinterpret_cast<f32x4*>(logits + (long)(4 + tl) * V + (long)(first + sa) * 4) = o;
     }
   }
 }
@@ -951,7 +977,7 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
 // squares ([rows][ssq_stride], `groups` valid), logits: fp32 [rows][V].
 extern "C" int umb_head_stream_ok(int rows, int V, int H) {
   static const bool off = getenv("UMB_NO_HEAD_STREAM") != nullptr;
-  if (off || rows < 1 || rows > 4 || H != 2048 || V % 4 || V < 4 * 256 * 8) return 0;
+  if (off || rows < 1 || rows > 8 || H != 2048 || V % 4 || V < 4 * 256 * 8) return 0;
   static int ncu = -1;
   if (ncu < 0) {
     int dev = 0;
@@ -961,7 +987,8 @@ extern "C" int umb_head_stream_ok(int rows, int V, int H) {
   return ncu == 256;
 }
 extern "C" int umb_head_stream(float* logits, const void* x, const float* ssq, int ssq_stride, int groups, float eps,
-                               const void* w_rows, int rows, int V, int H, int dtype, hipStream_t st) {
+                               const void* w_rows, int rows, int V, int H, int x_fm_tt, int dtype, hipStream_t st) {
+  if (x_fm_tt < 0 || (x_fm_tt && x_fm_tt * 16 < rows)) return UMB_EINVAL;
   if (!umb_head_stream_ok(rows, V, H) || !logits || !x || !ssq || !w_rows || groups < 1 || groups > 256 || groups > ssq_stride) return UMB_EINVAL;
   const int R = 8;                                      // ring: 8 x 16 KiB; the operand rows live in registers
   const unsigned off_flags = (unsigned)R * CH_SLOT;
@@ -976,10 +1003,11 @@ extern "C" int umb_head_stream(float* logits, const void* x, const float* ssq, i
       once = true;                                                                                                               \
     }                                                                                                                            \
     hipLaunchKernelGGL((draft_head_kernel<PT, TTV>), dim3(256), dim3(256), lds, st, (const char*)w_rows, R, off_flags, V / 4, ticks, \
-                       (const u16*)x, ssq, ssq_stride, groups, eps, logits, rows, V);                                            \
+                       (const u16*)x, ssq, ssq_stride, groups, eps, logits, rows, V, x_fm_tt);                                         \
   } while (0)
   DISPATCH_DTYPE(dtype, {
-    if (rows == 1) UMB_HEAD_(P, 1); else if (rows == 2) UMB_HEAD_(P, 2); else if (rows == 3) UMB_HEAD_(P, 3); else UMB_HEAD_(P, 4);
+    if (rows == 1) UMB_HEAD_(P, 1); else if (rows == 2) UMB_HEAD_(P, 2); else if (rows == 3) UMB_HEAD_(P, 3); else if (rows == 4) UMB_HEAD_(P, 4);
+    else if (rows == 5) UMB_HEAD_(P, 5); else if (rows == 6) UMB_HEAD_(P, 6); else if (rows == 7) UMB_HEAD_(P, 7); else UMB_HEAD_(P, 8);
   })
 #undef UMB_HEAD_
   UMB_LAUNCH_CHECK();

@@ -280,6 +280,11 @@ static int head_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
   // the same FM activations and sums of squares (round 4: 1B head at 16 rows 116 -> 9x us; the whole-K kernel re-reads the
   // activations once per wave).  UMB_LL_HEAD=ll: the whole-K kernel (A/B).  Shape-only + head_from, so batch invariance is kept.
   static const char* env = getenv("UMB_LL_HEAD");
+  // a draft's 5 ... 8-row levels (the reference's 5- and 6-wide Sequoia trees): the streaming engine of chain.hip reads the same
+  // FM activations and sums of squares
+  if (s->head_from == 0 && m->lm_head.w_rows && ssq_groups <= 256 && umb_head_stream_ok(s->T, m->lm_head.N, m->H))
+    return umb_head_stream(ws->logits, ws->hw, ws->ssq, ws->ssq_stride, ssq_groups, m->eps, m->lm_head.w_rows, s->T, m->lm_head.N,
+                           m->H, umb_ll_token_tiles(s->T), m->dtype, st);
   if (!(env && env[0] == 'l') && s->head_from == 0 && m->lm_head.S == 1 && !m->lm_head.awq && ssq_groups % 4 == 0 &&
       ws->ssq_stride % 4 == 0) {
     UmbGemmFused fs = {};
@@ -391,7 +396,7 @@ static int head_gv(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, 
   // the head's rows as a plain row-major table (a tied model's embedding table): the streaming engine of chain.hip
   if (m->lm_head.w_rows && umb_head_stream_ok(rows, m->lm_head.N, m->H))
     return umb_head_stream(ws->logits, x, ws->ssq + (size_t)s->head_from * ws->ssq_stride, ws->ssq_stride, groups, m->eps,
-                           m->lm_head.w_rows, rows, m->lm_head.N, m->H, m->dtype, st);
+                           m->lm_head.w_rows, rows, m->lm_head.N, m->H, 0, m->dtype, st);
   UmbGemmFused fh = {};
   fh.ssq_in = ws->ssq + (size_t)s->head_from * ws->ssq_stride; fh.ssq_groups = groups; fh.pad0 = ws->ssq_stride;
   fh.ssq_dim = (float)m->H; fh.eps = m->eps;
