@@ -76,13 +76,16 @@ template <int NT, int DEPTH> static float run(const char* buf, size_t bytes, int
   return ms / reps * 1e3f;   // us per launch
 }
 
-int main() {
+int main(int argc, char** argv) {
   const size_t bytes = (size_t)2 << 30;
   char* buf;
   CK(hipMalloc(&buf, bytes));
   CK(hipMemset(buf, 1, bytes));
   printf("LDS-DMA fill probe: 256 workgroups (1 per CU), 16 KiB slots, us per launch -> TB/s, us per slot per CU\n");
-  for (int slots : {29, 116}) {            // 29 = one 1B layer's chain; 116 = four layers' worth
+  std::vector<int> slot_list = {29, 116};  // 29 = one 1B layer's chain; 116 = four layers' worth
+  if (argc > 1) { slot_list.clear(); for (int i = 1; i < argc; ++i) slot_list.push_back(atoi(argv[i])); }   // e.g. 9 11 30 61: the 70B o / qkv / down / gate-up footprints
+  const bool only = getenv("ONLY") != nullptr;   // ONLY=1: the shipped variant alone (under rocprofv3: its kernel durations per footprint)
+  for (int slots : slot_list) {
     const double mb = 256.0 * slots * SLOT / 1e6;
     printf("-- %d slots per CU (%.1f MB per launch)\n", slots, mb);
     struct V { const char* name; int nt, depth, nl, ring, layout, skew; };
@@ -99,6 +102,7 @@ int main() {
       {"nt  depth4 4 loaders contiguous skewed", 1, 4, 4, 8, 0, 1},
       {"nt  depth2 4 loaders contiguous skewed", 1, 2, 4, 8, 0, 1},
     };
+    if (only) vs = {vs[1]};
     for (auto& v : vs) {
       float us = 0;
       if (v.nt && v.depth == 4) us = run<1, 4>(buf, bytes, slots, v.nl, v.ring, v.layout, v.skew);
