@@ -391,7 +391,7 @@ def context_sweep(eng, wl, gm, acc, args):
     44 GB do not change).  Bounded step counts; a failure here never takes the headline with it."""
     from umbrella_amd.speculation.steering import steered_measure
     out = {}
-    lengths = [64, 256, 512, max(512, args.max_length - 512)]
+    lengths = [64, 256, 512, max(512, min(args.max_length, 2048) - 512)]
     if os.environ.get("UMB_BENCH_CONTEXTS"):                       # experiments: "512,900"
         lengths = [int(v) for v in os.environ["UMB_BENCH_CONTEXTS"].split(",")]
     steps = int(os.environ.get("UMB_BENCH_CONTEXT_STEPS", 16))
@@ -756,6 +756,13 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["UMB_BENCH_STACKS"]), repeat=False)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    # A run of K timed iterations emits up to depth + 1 tokens in each: the reference's max_length 2048 holds ~370 iterations of the
+    # 3x4 tree behind a 128-token prompt.  Longer runs get the KV capacity they need (reported as config.max_length) instead of
+    # stopping inside the timed loop.
+    need_len = args.prompt_len + (args.warmup + args.steps + 4) * 7 + 64
+    if need_len > args.max_length:
+        args.max_length = (need_len + 1023) // 1024 * 1024
+        print(f"bench.py: --steps {args.steps} needs a context of {need_len} tokens: max_length raised to {args.max_length}", file=sys.stderr)
     self_launch(args)                                   # N > 1 outside torch.distributed.run: re-exec with N ranks
 
     rank, world, local = dist_env()
