@@ -1,6 +1,8 @@
 #!/bin/bash
 # 70B verify layer at T = 13 (graph-replayed 16-layer forward, split schedule): plan overrides of o / qkv / down, per-kernel durations
 # from the profiler.  tb byte: low 6 bits tiles per block, 0x40 = 4 k-blocks per chunk (8-stage weight ring), 0x80 = 8 waves per block.
+# NOTE: the 0x40 bit (a deeper weight ring for one linear) was an experiment hook of this round and is not in the product: see
+# profiles/r05_plan_sweep_70b_negative.txt; without it the 0x40 values below are rejected as tile counts (the plan stays as shipped).
 root=$(cd "$(dirname "$0")/../.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 run() {
