@@ -34,6 +34,11 @@ __host__ __device__ __forceinline__ long vt_off(int d, int p, int D) {
   return (((long)(p >> 5) * (D >> 4) + (d >> 4)) * 64 + ((p >> 3) & 3) * 16 + (d & 15)) * 8 + (p & 7);
 }
 
+// cache policy of stores whose data the NEXT kernel reads on other XCDs (buffer-store aux bits: 16 = sc1, write-through)
+#ifndef UMB_HANDOFF_AUX
+#define UMB_HANDOFF_AUX 16
+#endif
+
 #define UMB_OK 0
 #define UMB_EINVAL (-22)
 #define UMB_EHIP (-5)

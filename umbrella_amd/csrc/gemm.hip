@@ -553,7 +553,11 @@ __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __re
               v *= inv[tt];
               v[0] = rnd<P>(v[0]); v[1] = rnd<P>(v[1]); v[2] = rnd<P>(v[2]); v[3] = rnd<P>(v[3]);
             }
-            *reinterpret_cast<f32x4*>(out + ((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) = v;
+{   // write-through (sc1): the partials are read by the NEXT kernel on other XCDs -- nothing is left for the end-of-kernel
+              // write-back to drain (70B layer at T = 13: -1.2 us, profiles/r05_handoff_stores.txt); same bits, another cache policy
+              const auto rso = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rso, (int)((((long)sp * Ttot + tok) * N + (nt0 + r) * 16 + g * 4) * 4), 0, UMB_HANDOFF_AUX);
+            }
           }
         }
       }
@@ -1581,6 +1585,7 @@ extern "C" int umb_gemm_fused(void* out, const void* x, int ldx, const void* wpa
   static const int tb_env = getenv("UMB_TB") ? atoi(getenv("UMB_TB")) : 0;     // experiments
   if (tb_env > 0) tb = tb_env;
   if (N % 16 || K % 128 || T < 1 || S < 1 || epi < 0 || epi > 4 || (epi == EPI_SILU && S != 1)) return UMB_EINVAL;
+  if ((long)S * T * N * 4 >= (1L << 31)) return UMB_EINVAL;              // fp32 partials are stored through a 32-bit buffer offset
   if (awq && (N % 64 || (R != 1 && (N / 16) % 2))) return UMB_EINVAL;
   if ((tb & 0x7f) > ((tb & 0x80) ? 8 : 4) * R) tb = 0;
   GemmFused fx = {};
