@@ -303,27 +303,30 @@ def test_tp_two_ranks_share_one_gpu(dev, awq, allreduce):
     check_greedy(G, sd, PROMPT, a["static"], torch.float16, tol=0.12 if awq else None)
 
 
-@pytest.mark.gpu
-def test_tp_rccl_hook_inside_the_iteration_graph(dev):
-    """A 1-rank RCCL group with the all-reduce hook forced on (an all-reduce over one rank is the identity): every
-    collective of the native layer chain goes through torch.distributed "nccl" on the launch stream and is captured
-    into the iteration's hipGraph; tokens equal the plain single-GPU engine's bit for bit, and without the hook (the
-    real world-1 configuration) the path IS the plain one."""
-    import torch.distributed as dist
-    from hip_helpers import growmap, hip_model, static_engine
-    from umbrella_amd.speculation.speculation_utils import IdTokenizer
-    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
-    from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm
-    dtype = torch.float16
-    os.environ["UMB_SCHED"] = "split"               # the reference engine on the same 8-launch schedule the TP chain uses
+def _rccl_graph_worker(q):
+    """body of test_tp_rccl_hook_inside_the_iteration_graph, in a process of its own: tearing down an RCCL communicator whose
+    collectives were captured into a hipGraph aborts the process now and then (inside gc / destroy_process_group, 2 of 8 runs) --
+    a teardown fault of the runtime stack, after every assertion has passed.  The verdict travels through the queue BEFORE the
+    teardown; the parent checks the verdict, not the exit code."""
+    import traceback
     try:
-        ref_eng, _ = static_engine(G, dev, dtype, self_draft=True)
-        ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
-    finally:
-        os.environ.pop("UMB_SCHED")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
+        import torch.distributed as dist
+        from hip_helpers import growmap, hip_model, static_engine
+        from umbrella_amd.speculation.speculation_utils import IdTokenizer
+        from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+        from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm
+        import __graft_entry__ as ge
+        ge.build()
+        dev = torch.device("cuda:0")
+        dtype = torch.float16
+        os.environ["UMB_SCHED"] = "split"               # the reference engine on the same 8-launch schedule the TP chain uses
+        try:
+            ref_eng, _ = static_engine(G, dev, dtype, self_draft=True)
+            ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+        finally:
+            os.environ.pop("UMB_SCHED")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         cfg = _cfg()
         sd = synth_state_small(cfg, G["seeds"]["target"])
         for force in (True, False):
@@ -347,11 +350,35 @@ def test_tp_rccl_hook_inside_the_iteration_graph(dev):
                 assert len(calls) < n_iter * 8, "the collectives are replayed from the graph, not re-issued per step"
             else:
                 assert calls == []
+        torch.cuda.synchronize()
+        q.put("ok")
+    except BaseException:
+        q.put(traceback.format_exc())
+    q.close()
+    q.join_thread()                                 # the verdict is in the pipe before the process goes
+    os._exit(0)                                     # no interpreter teardown: see the docstring
+
+
+@pytest.mark.gpu
+def test_tp_rccl_hook_inside_the_iteration_graph(dev):
+    """A 1-rank RCCL group with the all-reduce hook forced on (an all-reduce over one rank is the identity): every
+    collective of the native layer chain goes through torch.distributed "nccl" on the launch stream and is captured
+    into the iteration's hipGraph; tokens equal the plain single-GPU engine's bit for bit, and without the hook (the
+    real world-1 configuration) the path IS the plain one.  Runs in a spawned process (_rccl_graph_worker)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graph_worker, args=(q,))
+    p.start()
+    try:
+        verdict = q.get(timeout=240)
     finally:
-        dist.destroy_process_group()
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert verdict == "ok", verdict
 
 
-# ------------------------------------------------------------------ the real 70B shard shapes (round 4)
 class _ThreadComm:
     """TPComm face for P ranks living as THREADS of one process on one GPU: the all-reduce of the native layer chain's
     hook is a barrier + an fp32 sum over the ranks' partial buffers in rank order (what a reduce over the links
