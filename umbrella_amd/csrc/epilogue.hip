@@ -8,6 +8,9 @@
 //   q/k/v view + RoPE at tree positions (model_utils.py:17-52) + KV append (attn/cache.py:53-65)
 //   embedding gather (F.embedding, llama.py:124)
 #include "common.h"
+// split-K partials are read exactly once, by a kernel on other XCDs than their writers: non-temporal loads (70B layer at T = 13:
+// -0.7 us over its two residual reduces; profiles/r05_handoff_stores.txt)
+#define LDP(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
 
 // ---- plain RMSNorm over rows of 16-bit x (also the standalone umb_rmsnorm op)
 template <typename P>
@@ -76,10 +79,10 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
     f32x4 v0[8], v1[8];                                        // deep: v1 = splits 8..15 of group 0
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) {
-      v0[s2] = (ok0 && s2 < S) ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i0 + (long)s2 * sstride) : z;
+      v0[s2] = (ok0 && s2 < S) ? LDP(part + (long)t * N + i0 + (long)s2 * sstride) : z;
       const bool use1 = deep ? (ok0 && s2 + 8 < S) : (ok1 && s2 < S);
       const long off1 = deep ? (long)t * N + i0 + (long)(s2 + 8) * sstride : (long)t * N + i1 + (long)s2 * sstride;
-      v1[s2] = use1 ? *reinterpret_cast<const f32x4*>(part + off1) : z;
+      v1[s2] = use1 ? LDP(part + off1) : z;
     }
     const uint2 z2 = {0u, 0u};
     const uint2 r0 = (residual && ok0) ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i0) : z2;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(1024) void reduce_residual_norm_kernel(const float*
       f32x4 v[8];
 #pragma unroll
       for (int s2 = 0; s2 < 8; ++s2)
-        v[s2] = s2 < S ? *reinterpret_cast<const f32x4*>(part + (long)t * N + i + (long)s2 * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[s2] = s2 < S ? LDP(part + (long)t * N + i + (long)s2 * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
       a = v[0];
 #pragma unroll
       for (int s2 = 1; s2 < 8; ++s2)
