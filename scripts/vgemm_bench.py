@@ -35,10 +35,15 @@ for name, N, K, il in (("qkv", 10240, 8192, 0), ("o", 8192, 8192, 0), ("gu", 573
         launch(i)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for i in range(20):
+    if os.environ.get("STAMP"):
+        import time; print(f"{time.time():.3f} start {name}", flush=True)
+    loops = int(os.environ.get("LOOPS", "20"))
+    for i in range(loops):
         launch(i + 3)
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 20
+    us = e0.elapsed_time(e1) * 1e3 / loops
+    if os.environ.get("STAMP"):
+        print(f"{time.time():.3f} end {name} {us:.1f} us", flush=True)
     tot += us
     res.append(f"{name} {us:6.1f} us ({2.0 * T * N * K / us / 1e6:6.0f} TF, S={S})")
     del lins

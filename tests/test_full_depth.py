@@ -324,3 +324,110 @@ def test_c3_offloaded_equals_resident(ncl):
     got = run(target)
     _drop(lambda k: k[0] == T70)                                # releases the pinned host slabs as well
     assert got == _cache["resident_trace"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at its own workload (round 6): Llama-3.3-70B-AWQ layer-sharded over EIGHT stages, 10 layers each,
+# the 1B draft on stage 0, static 3x4, greedy (umbrella_amd/parallel.py build_pipelined_engine).  A test box
+# has one GPU, so the eight stage processes share it and the seven hops per forward travel through pinned host buffers
+# over gloo; kernels, their order and the per-stage hipGraphs are those of an 8-GPU run -- only the transport differs.
+C5_NEW = 40
+
+
+def _c5_worker(rank, world, port, q, prompt, steer):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as ge
+    ge.build()
+    from umbrella_amd.parallel import build_pipelined_engine, shutdown_pipeline
+    from umbrella_amd.sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    eng = build_pipelined_engine("cuda:0", dtype=torch.float16, engine="static", model=T70, draft_model=D1B,
+                                 growmap=generate_sequoia_tree(3, 4), max_length=512, exit_layer=16, safe_buffer=16,
+                                 tokenizer=IdTokenizer())
+    if eng is not None:
+        raw = eng.generate(input_ids=prompt, max_new_tokens=C5_NEW)
+        # steered draft: the single-process engine's fixed-point continuation placed in the tree (bench.py's knob)
+        assert eng._prefill(torch.tensor([prompt]))
+        start = eng.num_nodes
+        eng.set_oracle_draft(steer, start, DEFAULT_ACC, seed=0)
+        steps = 0
+        while eng.num_nodes - start < C5_NEW and eng.validate_status():
+            eng.step()
+            steps += 1
+        torch.cuda.synchronize()
+        tk = eng.tokens[start:start + C5_NEW + 1].tolist()
+        accept = (eng.num_nodes - start) / max(steps, 1)
+        hop_bytes = eng.tree_size * eng._stage_model.config.hidden_size * 2
+        eng.reset()
+        shutdown_pipeline(eng)
+        q.put(dict(raw=raw["generated_tokens"], raw_accept=raw["avg_accept_tokens"], steered=tk, accept=accept,
+                   diverged=eng.diverged, layers_per_rank=eng._stage_model.num_layers, hop_bytes=hop_bytes,
+                   tree_size=eng.tree_size))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_70b_awq_eight_stages():
+    """BASELINE config 5: eight processes x 10 of the 70B-AWQ's 80 layers (4.5 GB of int4 each), draft = all 16 layers of
+    the 1B on stage 0, Sequoia 3x4 (T = 13: 13 x 8192 x 2 B = 213 KB per hop).  Token ids == the single-process headline
+    engine's (default schedules, persistent draft chain included) for >= 40 tokens, with the raw random draft and with
+    the steered one."""
+    import socket
+    import torch.multiprocessing as mp
+    import __graft_entry__ as ge
+    ge.build()
+    from umbrella_amd.sequoia_utils import DEFAULT_ACC, generate_sequoia_tree
+    from umbrella_amd.speculation.speculation_utils import IdTokenizer
+    from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
+    dev = torch.device("cuda:0")
+    _drop(lambda k: True)                                             # the module's cached 70B / drafts: eight stages need the room
+    prompt = _prompt()
+    ref = StaticSpeculationEngine(D1B, T70, dtype=torch.float16, device=str(dev), growmap=generate_sequoia_tree(3, 4),
+                                  max_length=512, exit_layer=16, safe_buffer=16, tokenizer=IdTokenizer())
+    ref.initialize()
+    raw = ref.generate(input_ids=prompt, max_new_tokens=C5_NEW)
+    truth = _ar(ref.target_model, prompt, C5_NEW + 16, dev)
+    for _ in range(8):                                                # fixed point of the steered run, as in _run_pair
+        assert ref._prefill(torch.tensor([prompt]))
+        start = ref.num_nodes
+        ref.set_oracle_draft(truth, start, DEFAULT_ACC, seed=0)
+        steps = 0
+        while ref.num_nodes - start < C5_NEW and ref.validate_status():
+            ref.step()
+            steps += 1
+        accept, div = (ref.num_nodes - start) / max(steps, 1), ref.diverged
+        while ref.num_nodes - start < C5_NEW + 16 and ref.validate_status():
+            ref.step()
+        tk = ref.tokens[start:start + C5_NEW + 1].tolist()
+        steer = truth
+        truth = ref.tokens[start:ref.num_nodes + 1].tolist()
+        ref.reset()
+        if div == 0:
+            break
+    assert div == 0
+    del ref
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c5_worker, args=(r, 8, port, q, prompt, steer)) for r in range(8)]
+    for p in procs:
+        p.start()
+    try:
+        got = q.get(timeout=900)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert got["layers_per_rank"] == 10 and got["tree_size"] == 13 and got["hop_bytes"] == 13 * 8192 * 2
+    assert len(got["raw"]) >= C5_NEW and got["raw"] == raw["generated_tokens"]
+    assert got["steered"] == tk and got["diverged"] == 0 and abs(got["accept"] - accept) < 1e-9 and accept > 2.0
+    report_fact("full_depth/C5 70B-AWQ x 8 stages", dict(layers_per_rank=got["layers_per_rank"], hop_bytes=got["hop_bytes"],
+                tokens_raw=len(got["raw"]), tokens_steered=len(got["steered"]), accept_steered=got["accept"],
+                raw_accept=got["raw_accept"], equals_single_process=True))

@@ -267,7 +267,7 @@ __device__ __forceinline__ void stage_compute(const Stage<P, AWQ, R>& st, const 
   }
 }
 
-enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 };
+#include "gemm_fused.h"
 
 // -DUMB_GEMM_TRACE (scripts/r3/gemm_trace.py builds a second library with it): wave 0 of every block stamps the constant
 // 100 MHz clock at its phase boundaries into fx.counters (16 x u64 per block; unused by the direct epilogues): 0 entry,
@@ -279,22 +279,6 @@ enum { EPI_PARTIAL = 0, EPI_ROUND = 1, EPI_SILU = 2, EPI_QKV = 3, EPI_RESID = 4 
 #else
 #define UMB_STAMP(i) do {} while (0)
 #endif
-
-// Optional fused work around the GEMM (all pointers may be null).  Passed by value.
-//  * ssq_in : [T][ssq_groups] partial sums of squares of the producer's residual stream.  The RMSNorm weight is
-//    already folded into x by the producer (x = h * w), the per-token factor rsqrt(mean(h^2) + eps) commutes with
-//    the matmul and is applied to the outputs here (epi 1, 2, 3).
-//  * epi 3 / 4 with S > 1: every split block publishes its fp32 partial tile, the LAST block to arrive on the
-//    n-group's counter sums the S partials in split order (deterministic) and runs the epilogue -- no reduce kernel.
-struct GemmFused {
-  int ssq_stride;          // row stride of ssq_in (0: ssq_groups)
-  int x_fm, out_fm;        // x / the SiLU output in FM (MFMA B-fragment) layout, lowlat.hip: the low-latency schedule's buffers
-  const float* ssq_in; int ssq_groups; float ssq_dim; float eps;
-  unsigned* counters;
-  u16* h; u16* hw; const u16* norm_w; float* ssq_out; int ssq_out_stride;    // epi 4
-  const int* pos; const int* slot; const u16* cosT; const u16* sinT;          // epi 3
-  u16* q_out; u16* kc; u16* vt; int Hq, Hkv, D, Lmax;
-};
 
 template <typename P, int AWQ, int TT, int R, int CB, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void skinny_gemm_kernel(const u32x4* __restrict__ wp,
@@ -1519,6 +1503,9 @@ static int launch_tt(const void* wp, const void* meta, const u16* x, int ldx, fl
   if constexpr (AWQ != 1) {
     static const bool no_vgemm = getenv("UMB_NO_VGEMM") != nullptr;     // diagnostic: 64-token chunks only
     if (T > 64 && N % 128 == 0 && epi <= EPI_SILU && !no_vgemm) {
+      // round 6: 32-row x whole-chunk waves, LDS-DMA activations (vgemm.hip); UMB_VGW=0: the kernels below
+      if constexpr (AWQ == 2 && std::is_same<P, F16>::value)
+        if (umb_vgemm_w_ok(T, N, K, S, epi)) return umb_vgemm_w(wp, meta, x, ldx, out, T, N, K, S, epi, fx0, st);
       const int rem = T % 128;
       // T = w d + 1 (257, 385, 769 ...): 144-token blocks swallow the short tail in the same number of chunks
       const int nc9 = (T + 143) / 144;
