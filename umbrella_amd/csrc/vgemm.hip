@@ -37,6 +37,11 @@ __device__ __forceinline__ unsigned vg_and_or(unsigned a, unsigned mask, unsigne
   return r;
 }
 
+#ifdef UMB_VGW_WNT
+#define VGW_WNT " nt"
+#else
+#define VGW_WNT ""
+#endif
 // one LDS-DMA piece: 64 lanes x 16 B, global address = sbase + voff (per lane), LDS address = ldsaddr + 16 * lane
 __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned ldsaddr) {
   unsigned keep;
@@ -49,8 +54,8 @@ __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned
 __device__ __forceinline__ void dma16x2(unsigned voff, const void* sbase, unsigned ldsaddr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\t"
-               "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2" VGW_WNT "\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:1024" VGW_WNT "\n\t"
                "s_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldsaddr) : "memory");
 }
@@ -77,6 +82,9 @@ template <int N> __device__ __forceinline__ void vg_wait() {
 }
 
 // TT = token tiles (of 16) per work item; a work item = 256 rows x TT tiles x one K slab.
+// (A 4-slot ROLLING variant -- the hand-over barrier BD pairs before the end of a step, B-fragment prefetch running across the
+// step boundary -- was built and measured: bit-identical, +1.8 % on zero activations, +-1 % on random ones; not kept.
+// profiles/r06_vgemm_w_experiments.txt)
 template <int TT>
 __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ wp, const unsigned char* __restrict__ meta,
                                                       const u16* __restrict__ x, int ldx, int T, int Tv, int N, int K, int S,
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
   const int kb0 = sp * per, kb1 = min(KB, sp * per + per);
 
   const unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
-  const unsigned wst0 = lds0 + 3u * SLOT + (unsigned)wv8 * (2u * VGW_WSTAGE);
+  constexpr unsigned NSLOT = 3u, WSTAGES = 2u;
+  const unsigned wst0 = lds0 + NSLOT * SLOT + (unsigned)wv8 * (WSTAGES * VGW_WSTAGE);
 
   f32x4 acc[2][TT];
 #pragma unroll
@@ -132,11 +141,18 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
   // branch: a wave without an NPW-th piece of its own (NP is not always a multiple of 8) fetches its first piece again
   // into a dump KiB behind the ring.
   const bool full = wv8 < NFULL;
-  const unsigned dump = lds0 + 3u * SLOT + 8u * 2u * VGW_WSTAGE;
+  const unsigned dump = lds0 + NSLOT * SLOT + 8u * WSTAGES * VGW_WSTAGE;
   // piece i of this wave for 64-k step s -> ring slot pos
   auto issue_b1 = [&](int s, int pos, int i) {
+#ifdef UMB_VGW_ABL_XHOT       // ablation (wrong results): every step re-reads the first 64 k of x (cache-hot source)
+    const u16* xs = x + (long)(min(s, 2 * kb1 - 1) & 1) * 64;
+#else
     const u16* xs = x + (long)min(s, 2 * kb1 - 1) * 64;
+#endif
     const unsigned dst = lds0 + (unsigned)pos * SLOT + (unsigned)wv8 * 1024u + (unsigned)i * 8192u;
+#if defined(UMB_VGW_ABL_NODMA) || defined(UMB_VGW_ABL_NOX)     // ablation (wrong results): the prologue's loads only
+    if (s > 2 * kb0 + 1) return;
+#endif
     dma16(vx[i], xs, (i == NPW - 1 && !full) ? dump : dst);
   };
   auto issue_b = [&](int s, int pos) {
@@ -147,6 +163,9 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
   auto issue_w1 = [&](int kb, int part) {
     const int kk = min(kb, kb1 - 1);
     const unsigned dst = wst0 + (unsigned)(kb & 1) * VGW_WSTAGE;
+#if defined(UMB_VGW_ABL_NODMA) || defined(UMB_VGW_ABL_NOW)
+    if (kb > kb0 + 1) return;
+#endif
     if (part == 0) dma16x2(vw, wsrc + (long)kk * 4096, dst);
     else dma4(vm, msrc + (long)kk * 256, dst + 2048u);
   };
@@ -180,6 +199,10 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
     const int q = idx >> 3, sx = (idx >> 2) & 1, d = idx & 3;
     const unsigned w = raw[q][hf * 2 + sx];
     const unsigned ws = (d & 2) ? (w >> 8) : w;
+#ifdef UMB_VGW_ABL_NODEQ      // ablation (wrong results): raw bits as the operand
+    dst[q][sx][d] = ws;
+    return;
+#endif
     if (d & 1) {
       const h2 c = __builtin_bit_cast(h2, vg_and_or(ws, 0x00F000F0u, magic));
       dst[q][sx][d] = __builtin_bit_cast(unsigned, __builtin_elementwise_fma(c, sixteenth, nz16_2[q]) * s2[q]);
@@ -212,7 +235,9 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
     const int s = 2 * kb + HF;
     // this step's activations (and, on odd steps, the next block's weights) have landed; the newest group stays in flight
     if (HF == 0) VGW_WAIT(3); else VGW_WAIT(0);
+#ifndef UMB_VGW_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     const int p2 = pos == 0 ? 2 : pos - 1;         // (pos + 2) % 3: the slot every wave finished reading before this barrier
 #if !UMB_VGW_SPREAD
     issue_b(s + 2, p2);
@@ -237,9 +262,16 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
     for (int i = 0; i < NP; ++i) {
       int tt, sx;
       frag_of(i, tt, sx);
+#ifdef UMB_VGW_ABL_NOLDS      // ablation (wrong results): the first BD fragments only
+      if (false)
+#endif
       if (i + BD < NP) { int t2, s2x; frag_of(i + BD, t2, s2x); bq[(i + BD) % (BD + 1)] = bp[s2x][t2 * 128]; }
+#ifdef UMB_VGW_ABL_NOMFMA     // ablation (wrong results)
+      asm volatile("" :: "v"(bq[i % (BD + 1)]), "v"(wcur[0][sx]), "v"(wcur[1][sx]));
+#else
 #pragma unroll
       for (int q = 0; q < 2; ++q) acc[q][tt] = P::mfma(wcur[q][sx], bq[i % (BD + 1)], acc[q][tt]);
+#endif
       // the next step's weight fragments (16 dwords of two weights each), spread evenly over the step's MFMA pairs
 #pragma unroll
       for (int k = (i * 16) / NP; k < ((i + 1) * 16) / NP; ++k) deq1(wnext, HF ^ 1, k);
@@ -305,6 +337,10 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
 
 // ------------------------------------------------------------------ host side
 // Work split of a wide launch: NT = ceil(T / 16) token tiles in `nchunk` chunks of TT = ceil(NT / nchunk) <= 18 tiles.
+static inline int vgw_ver() {
+  static const int v = getenv("UMB_VGW") ? atoi(getenv("UMB_VGW")) : 1;
+  return v;
+}
 static inline void vgw_shape(int T, int* nchunk, int* tt) {
   const int NT = (T + 15) / 16;
   int nc = (NT + 17) / 18;
@@ -313,8 +349,7 @@ static inline void vgw_shape(int T, int* nchunk, int* tt) {
 }
 
 extern "C" int umb_vgemm_w_ok(int T, int N, int K, int S, int epi) {
-  static const bool off = getenv("UMB_VGW") != nullptr && atoi(getenv("UMB_VGW")) == 0;
-  if (off || T <= 64 || N % 256 || K % 128 || epi > EPI_SILU || S < 1 || S > K / 128) return 0;
+  if (vgw_ver() == 0 || T <= 64 || N % 256 || K % 128 || epi > EPI_SILU || S < 1 || S > K / 128) return 0;
   int nc, tt;
   vgw_shape(T, &nc, &tt);
   if (tt < 5) return 0;
