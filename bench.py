@@ -481,17 +481,27 @@ def secondary_configs(device, seed=0):
         return shared["t"]
 
     def pmc_mfma_busy(T):
-        """MFMA-busy of the wide verify GEMM from the COMMITTED counter pass of this build's kernel (PMC cannot be read from
-        inside the timed process: `scripts/collect_r04.sh` -> profiles/, summarised by scripts/pmc_mfma_busy.py).  Not live:
-        the file name travels with the figure."""
-        name = f"r04_pmc_verify_gemm_T{769 if T > 512 else 256}_mfma_busy.json"
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                ks = [k for k in json.load(f)["kernels"] if "verify_gemm_pp_kernel" in k["kernel"] and "mfma_busy" in k]
-            return {"source": f"profiles/{name} (committed rocprofv3 --pmc pass, not measured by this run)",
-                    "by_blocks": {str(k["blocks"]): k["mfma_busy"] for k in ks}}
-        except Exception:
-            return None
+        """MFMA-busy of the wide verify GEMM from a COMMITTED counter pass (PMC cannot be read from inside the timed process:
+        scripts/r6/pmc_mfma.sh -> profiles/, summarised by scripts/pmc_mfma_busy.py).  Reported only while the kernel sources the
+        pass ran on are the tree's (sha256/16 of csrc/gemm.hip and csrc/vgemm.hip recorded in the file); otherwise null."""
+        import glob
+        import hashlib
+        def h(f):
+            with open(os.path.join(ROOT, "umbrella_amd", "csrc", f), "rb") as fh:
+                return hashlib.sha256(fh.read()).hexdigest()[:16]
+        want = {"gemm_hip_sha256_16": h("gemm.hip"), "vgemm_hip_sha256_16": h("vgemm.hip")}
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_verify_gemm_T{769 if T > 512 else 256}_mfma_busy.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    rec = json.load(f)
+            except Exception:
+                continue
+            if any(rec.get(k) != v for k, v in want.items()):
+                continue                                   # taken on other kernel source: not this build's figure
+            ks = [k for k in rec["kernels"] if ("vgemm_w_kernel" in k["kernel"] or "verify_gemm" in k["kernel"]) and "mfma_busy" in k]
+            return {"source": f"profiles/{os.path.basename(path)} (committed rocprofv3 --pmc pass on this build's gemm.hip / vgemm.hip, "
+                              "not measured by this run)", "by_blocks": {str(k["blocks"]): k["mfma_busy"] for k in ks}}
+        return None
 
     def verify_rate(eng):
         """dense MFMA rate of the verify forward alone (events on the launch stream), 2 T (layer + head parameters) flops"""

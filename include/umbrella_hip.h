@@ -142,8 +142,10 @@ int umb_repack_rows(void* out, const void* w, int N, int K, int mode, int D, int
  * ssq[t][0 .. ssq_groups_in).  xchg: umb_chain_xchg_bytes(Tmax, H, I) device bytes, zeroed once, then the epoch word at
  * its end set to 1 (umb_chain_xchg_init); a launch that gives up on a hand-off (every spin is bounded: 20 ms, or
  * UMB_CHAIN_TIMEOUT_MS) ORs 0xDEADxxxx into the status word (umb_chain_status).  Needs every workgroup resident: one
- * process per device.  umb_chain_ok: 1 where the shape is covered (H 2048, I 8192, T <= 4, no q/k/v bias, 256 CUs;
- * 0 with UMB_NO_CHAIN=1). */
+ * process per device.  umb_chain_ok: 1 where the shape is covered (H 2048, I 8192, T <= 3, no q/k/v bias, 256 CUs;
+ * 0 with UMB_NO_CHAIN=1).  The exchange LAYOUT is fixed at UMB_CHAIN_TMAX rows whatever the forward's T or the workspace's
+ * Tmax: allocate umb_chain_xchg_bytes(UMB_CHAIN_TMAX, H, I), initialise and query with the same constant. */
+#define UMB_CHAIN_TMAX 4
 typedef struct UmbChain {
   const void* w_o; const void* w_gu; const void* w_down; const void* w_qkv;   /* umb_repack_rows copies */
   const void* attn; void* h; void* hw; float* ssq;
@@ -364,8 +366,10 @@ typedef struct UmbWorkspace {
   int32_t fused, pad_;              /* layer schedule: 0 = 8 launches (split-K reduced at kernel boundaries), 1 = 5 launches
                                        (in-kernel last-arriver reduces; slower), 2 = low-latency 5 launches (whole-K
                                        workgroups, FM activations; T <= 64 only, wider forwards use schedule 0) */
-  void* chain_xchg;                 /* NULL, or umb_chain_xchg_bytes(Tmax, H, I) bytes (umb_chain_xchg_init): forwards of
-                                       <= 4 rows of a GEMV-role model run the persistent chain (csrc/chain.hip) */
+  void* chain_xchg;                 /* NULL, or umb_chain_xchg_bytes(UMB_CHAIN_TMAX, H, I) bytes set up by
+                                       umb_chain_xchg_init(.., UMB_CHAIN_TMAX, ..) -- NOT this workspace's Tmax: the epoch and status
+                                       words sit behind a 4-row layout.  Forwards of <= 3 rows of a GEMV-role model then run the
+                                       persistent chain (csrc/chain.hip) */
 } UmbWorkspace;
 
 typedef struct UmbStep {

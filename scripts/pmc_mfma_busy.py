@@ -17,8 +17,9 @@ with open(src) as f:
         key = (name.split("(")[0][:80], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 import hashlib, os
-_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "umbrella_amd", "csrc", "gemm.hip")
-out = {"command": cmd, "gemm_hip_sha256_16": hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16], "notes": "means per launch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); "
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "umbrella_amd", "csrc")
+_h = lambda f: hashlib.sha256(open(os.path.join(_csrc, f), "rb").read()).hexdigest()[:16]
+out = {"command": cmd, "gemm_hip_sha256_16": _h("gemm.hip"), "vgemm_hip_sha256_16": _h("vgemm.hip"), "notes": "means per launch; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); "
        "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves", "kernels": []}
 for (name, blocks), ctr in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
     m = {c: sum(v) / len(v) for c, v in ctr.items()}

@@ -20,7 +20,7 @@ def _free_port():
 
 def _pp_worker(rank, world, port, q):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1", UMB_CHAIN="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as ge
     ge.build()
@@ -44,7 +44,7 @@ def test_two_stage_pipeline_equals_single_process():
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
-    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1"); os.environ["UMB_CHAIN"] = "0"
+    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")
     from umbrella_amd.sequoia_utils import generate_sequoia_tree
     from umbrella_amd.speculation.speculation_utils import IdTokenizer
     from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
@@ -80,7 +80,7 @@ def test_eight_stage_pipeline_equals_single_process():
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
-    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1"); os.environ["UMB_CHAIN"] = "0"
+    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")
     from umbrella_amd.sequoia_utils import generate_sequoia_tree
     from umbrella_amd.speculation.speculation_utils import IdTokenizer
     from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
@@ -114,7 +114,7 @@ DYN = dict(width=8, num_beams=8, depth=4, temperature=0.7, topp=0.9, topk=16, re
 
 def _pp_dynamic_worker(rank, world, port, q):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1", UMB_CHAIN="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UMBRELLA_SYNTHETIC="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as ge
     ge.build()
@@ -140,7 +140,7 @@ def test_two_stage_dynamic_stochastic_equals_single_process():
     import torch.multiprocessing as mp
     import __graft_entry__ as ge
     ge.build()
-    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1"); os.environ["UMB_CHAIN"] = "0"
+    os.environ.setdefault("UMBRELLA_SYNTHETIC", "1")
     from umbrella_amd.speculation.dynamic_speculation_engine import DynamicSpeculationEngine
     from umbrella_amd.speculation.speculation_utils import IdTokenizer
     ref = DynamicSpeculationEngine(NAME, NAME, dtype=torch.float16, device="cuda:0", max_length=512, exit_layer=4,

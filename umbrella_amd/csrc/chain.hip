@@ -867,17 +867,24 @@ static int chain_ring(int T) {
   return r > CH_MAXRING ? CH_MAXRING : r;
 }
 
+// Per-DEVICE facts and one-time settings (a process may drive several GPUs: the dynamic-LDS attribute and the CU count belong to
+// the device that is current at the call, not to the process).
+static inline int chain_dev() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : 0; }
+static inline int chain_ncu() {
+  static int ncu[64] = {};
+  const int d = chain_dev();
+  if (ncu[d] == 0) {
+    hipDeviceProp_t pr;
+    ncu[d] = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : -1;
+  }
+  return ncu[d];
+}
 extern "C" int umb_chain_ok(int T, int H, int I, int NQKV, int D, int has_bias) {
   static const bool off = getenv("UMB_NO_CHAIN") != nullptr;
   if (off || has_bias) return 0;
   // T = 4 would keep 256 operand registers for the down-projection (spills); 4-row levels stay on the GEMV launches
   if (T < 1 || T > 3 || H != 2048 || I != 8192 || NQKV % 1024 || D % 2) return 0;
-  static int ncu = -1;
-  if (ncu < 0) {
-    int dev = 0; hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) ncu = 0;
-    else ncu = pr.multiProcessorCount;
-  }
+  const int ncu = chain_ncu();
   // rows per CU in whole slots: 8 o / down rows (the GEMV family's sums-of-squares groups), whole 4-row q/k/v slots, one
   // q/k/v slot per consumer at most (its RoPE operands are loaded up front)
   if (ncu != 256) return 0;
@@ -952,7 +959,8 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
   if (c->front && c->ssq && c->ssq_stride < 256) return UMB_EINVAL;
 #define CH_GO(TTV)                                                                                                     \
   do {                                                                                                                 \
-    static bool attr_done = false;                                                                                     \
+    static bool attr_done_dev[64] = {};                                                                                \
+    bool& attr_done = attr_done_dev[chain_dev()];                                                                      \
     if (!attr_done) {                                                                                                  \
       if (hipFuncSetAttribute((const void*)draft_chain_kernel<P, TTV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               160 * 1024) != hipSuccess) return UMB_EHIP;                                              \
@@ -978,13 +986,7 @@ extern "C" int umb_draft_chain(const UmbChain* c, int dtype, hipStream_t st) {
 extern "C" int umb_head_stream_ok(int rows, int V, int H) {
   static const bool off = getenv("UMB_NO_HEAD_STREAM") != nullptr;
   if (off || rows < 1 || rows > 8 || H != 2048 || V % 4 || V < 4 * 256 * 8) return 0;
-  static int ncu = -1;
-  if (ncu < 0) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 0;
-  }
-  return ncu == 256;
+  return chain_ncu() == 256;
 }
 extern "C" int umb_head_stream(float* logits, const void* x, const float* ssq, int ssq_stride, int groups, float eps,
                                const void* w_rows, int rows, int V, int H, int x_fm_tt, int dtype, hipStream_t st) {
@@ -993,10 +995,14 @@ extern "C" int umb_head_stream(float* logits, const void* x, const float* ssq, i
   const int R = 8;                                      // ring: 8 x 16 KiB; the operand rows live in registers
   const unsigned off_flags = (unsigned)R * CH_SLOT;
   const unsigned lds = off_flags + F_WORDS * 4u;
-  static const unsigned ticks = 100000u * (unsigned)(getenv("UMB_CHAIN_TIMEOUT_MS") ? atoi(getenv("UMB_CHAIN_TIMEOUT_MS")) : 20);
+  // No give-up deadline here: this kernel's waits are between the loader wave and the consumer waves of ONE workgroup (no other
+  // workgroup, no residency assumption), so they always end; a deadline could only turn a slow launch into silently wrong logits
+  // (there is no status word on this path).  ~43 s of the 100 MHz clock = never.
+  const unsigned ticks = 0xFFFFFFFFu;
 #define UMB_HEAD_(PT, TTV)                                                                                                       \
   do {                                                                                                                           \
-    static bool once = false;                                                                                                    \
+    static bool once_dev[64] = {};                                                                                               \
+    bool& once = once_dev[chain_dev()];                                                                                          \
     if (!once) {                                                                                                                 \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&draft_head_kernel<PT, TTV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds) != hipSuccess) return UMB_EHIP;                                                          \

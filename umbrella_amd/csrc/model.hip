@@ -377,8 +377,8 @@ static int chain_launch(const UmbModel* m, const UmbWorkspace* ws, const UmbStep
   }
   c.NQKV = m->layers[lt >= 0 ? lt : lf].qkv.N;
   c.h = ws->h; c.hw = ws->hw; c.ssq = ws->ssq; c.next_norm = next_norm; c.xchg = ws->chain_xchg;
-  c.T = s->T; c.Tmax = 4;                    /* the exchange is sized for <= 4 rows (umb_chain_xchg_bytes(4, H, I)) */
-   c.H = m->H; c.I = m->I; c.ssq_stride = ws->ssq_stride; c.ssq_groups_in = groups_in;
+  c.T = s->T; c.Tmax = UMB_CHAIN_TMAX;       /* the exchange layout is fixed (umbrella_hip.h: UmbWorkspace.chain_xchg) */
+  c.H = m->H; c.I = m->I; c.ssq_stride = ws->ssq_stride; c.ssq_groups_in = groups_in;
   c.Hq = m->Hq; c.Hkv = m->Hkv; c.D = m->D; c.Lmax = m->Lmax; c.eps = m->eps;
   return umb_draft_chain(&c, m->dtype, st);
 }

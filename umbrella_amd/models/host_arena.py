@@ -66,11 +66,28 @@ class HostArena:
         self.bound = False
         if self.node >= 0 and self.nodes > 1:
             try:
-                numa = C.CDLL("libnuma.so.1")
+                numa = C.CDLL("libnuma.so.1", use_errno=True)
                 numa.numa_tonode_memory.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
                 if numa.numa_available() >= 0:
-                    numa.numa_tonode_memory(base, self.size, self.node)
-                    self.bound = True
+                    # PREFERRED, not strict: numa_tonode_memory binds under libnuma's current bind policy, and under a strict
+                    # bind a node without `size` free bytes sends the first-touch memset below to the OOM killer instead of
+                    # to this constructor's caller.  Bind only when the node really has the room, and say what happened.
+                    numa.numa_set_bind_policy.argtypes = [C.c_int]
+                    numa.numa_set_bind_policy(0)
+                    numa.numa_node_size64.argtypes = [C.c_int, C.POINTER(C.c_longlong)]
+                    numa.numa_node_size64.restype = C.c_longlong
+                    free = C.c_longlong(0)
+                    total = numa.numa_node_size64(self.node, C.byref(free))
+                    if total > 0 and free.value >= self.size + (1 << 30):
+                        C.set_errno(0)
+                        numa.numa_tonode_memory(base, self.size, self.node)      # (void in libnuma; failures surface in errno)
+                        if C.get_errno() == 0:
+                            self.bound = True
+                        else:
+                            self.notes.append(f"numa_tonode_memory errno {C.get_errno()}: first-touch placement")
+                    else:
+                        self.notes.append(f"node {self.node} has {free.value >> 20} MiB free of the {self.size >> 20} MiB wanted: "
+                                          "first-touch placement")
             except OSError:
                 self.notes.append("libnuma missing: first-touch placement")
         elif self.nodes <= 1:

@@ -46,6 +46,8 @@ def _align(n, a=256):
     return (n + a - 1) // a * a
 
 
+CHAIN_TMAX = 4        # include/umbrella_hip.h UMB_CHAIN_TMAX: the persistent chain's exchange layout is fixed at 4 rows
+
 class PackedLinear:
     """One linear layer in MFMA tile order (dense 16-bit or AWQ int4)."""
 
@@ -492,28 +494,53 @@ class Llama(LLMBase):
         """Persistent chain (csrc/chain.hip): with the draft role on and a covered shape (umb_chain_ok: 1B-class dense
         models, <= 3 rows, no q/k/v bias, a 256-CU device) the <= 3-row forwards run as tree attention + ONE persistent
         launch per layer.  The launch needs every workgroup resident, i.e. this process alone on the device:
-        UMB_CHAIN=0 keeps the five GEMV launches (runs that share one GPU between processes set it; a launch that cannot
-        complete gives up after 20 ms and the engines raise on its status word)."""
+        UMB_CHAIN=0 keeps the five GEMV launches.  A launch that cannot complete (a shared device) gives up after 20 ms and
+        sets the status word; the engines then call disable_chain(), repair the draft's KV rows and carry on with the
+        GEMV launches (engine_common.HipEngine._chain_fallback)."""
         c = self.config
         lib = _lib.load()
         on = (getattr(self, "gemv", False) and os.environ.get("UMB_CHAIN", "1") != "0" and self._tp is None
+              and not getattr(self, "_chain_disabled", False)
               and self._off is None and hasattr(self, "_ws")
               and all(getattr(ln, "w_rows", None) is not None for lins in self.layers for ln in lins.values()))
         has_bias = int(any(getattr(st, "qkv_bias", None) for st in self._layer_structs))
         nqkv = c.q_dim + 2 * c.num_key_value_heads * c.head_dim
         if on and lib.umb_chain_ok(1, c.hidden_size, c.intermediate_size, nqkv, c.head_dim, has_bias):
             if getattr(self, "_chain_xchg", None) is None:
-                n = lib.umb_chain_xchg_bytes(4, c.hidden_size, c.intermediate_size)
+                n = lib.umb_chain_xchg_bytes(CHAIN_TMAX, c.hidden_size, c.intermediate_size)
                 self._chain_xchg = torch.zeros(n, dtype=torch.uint8, device=self.device)
-                _lib.check(lib.umb_chain_xchg_init(self._chain_xchg.data_ptr(), 4, c.hidden_size, c.intermediate_size,
+                _lib.check(lib.umb_chain_xchg_init(self._chain_xchg.data_ptr(), CHAIN_TMAX, c.hidden_size, c.intermediate_size,
                                                    _lib.stream_ptr()), "umb_chain_xchg_init")
             self._ws.chain_xchg = self._chain_xchg.data_ptr()
-            off = 4 * (c.hidden_size // 2 + c.intermediate_size // 2 + c.hidden_size // 2) * 8 + 64
+            off = CHAIN_TMAX * (c.hidden_size // 2 + c.intermediate_size // 2 + c.hidden_size // 2) * 8 + 64
             self.chain_status_word = self._chain_xchg[off:off + 4].view(torch.int32)     # device view (engines copy it out)
         elif hasattr(self, "_ws"):
             self._ws.chain_xchg = 0
             self.chain_status_word = None
         self.chain = bool(hasattr(self, "_ws") and self._ws.chain_xchg)
+
+    def disable_chain(self):
+        """Take the persistent chain out of this model's forwards (the five GEMV launches run instead -- bit-identical by
+        tests/test_chain.py) and clear its give-up word.  Graphs captured with the chain in them must be dropped by the
+        caller.  reset_chain() brings it back."""
+        if hasattr(self, "_ws"):
+            self._ws.chain_xchg = 0
+        self.chain = False
+        self._chain_disabled = True
+        if getattr(self, "chain_status_word", None) is not None:
+            self.chain_status_word.zero_()
+        self.chain_status_word = None
+
+    def reset_chain(self):
+        """Re-initialise the exchange (a launch that gave up leaves stale granules behind) and re-enable the chain where the
+        shape is covered; a no-op for models without it."""
+        self._chain_disabled = False
+        if getattr(self, "_chain_xchg", None) is not None:
+            c = self.config
+            self._chain_xchg.zero_()
+            _lib.check(_lib.load().umb_chain_xchg_init(self._chain_xchg.data_ptr(), CHAIN_TMAX, c.hidden_size, c.intermediate_size,
+                                                       _lib.stream_ptr()), "umb_chain_xchg_init")
+        self._chain_setup()
 
     def chain_status(self) -> int:
         """Sticky give-up word of the persistent chain's bounded hand-off spins (0: every launch so far completed its
@@ -522,7 +549,7 @@ class Llama(LLMBase):
             return 0
         c = self.config
         out = C.c_uint32(0)
-        _lib.check(_lib.load().umb_chain_status(self._chain_xchg.data_ptr(), 4, c.hidden_size, c.intermediate_size,
+        _lib.check(_lib.load().umb_chain_status(self._chain_xchg.data_ptr(), CHAIN_TMAX, c.hidden_size, c.intermediate_size,
                                                 C.byref(out), _lib.stream_ptr()), "umb_chain_status")
         return int(out.value)
 

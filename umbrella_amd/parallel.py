@@ -603,6 +603,9 @@ class _PipelinedMixin:
         self._pending = True                          # broadcast with the next iteration's `cont` (or on leaving)
         self.draft_model.kv_cache.compact(self.res, self.path, self.max_path)
         self._stage_model.kv_cache.compact(self.res, self.path, self.max_path)
+        st = getattr(self.draft_model, "chain_status_word", None)
+        if st is not None:                            # the persistent chain's give-up word (HipEngine._commit / _chain_fallback)
+            self.res[7:8].copy_(st)
         self.res_host.copy_(self.res, non_blocking=True)
 
     def verify(self):

@@ -282,15 +282,35 @@ class HipEngine(BaseEngine):
             self.target_model.peer.reset_status()
             raise RuntimeError(f"tensor parallel: a peer never published its tile (status {st:#x}); the tokens of this "
                                "iteration are invalid -- the group is out of step or a rank died")
-        if self.res_host[7] != 0:
-            raise RuntimeError(f"the draft model's persistent chain gave up on a hand-off (status {int(self.res_host[7]) & 0xffffffff:#x}): "
-                               "its launches need the whole device (one process per GPU); set UMB_CHAIN=0 to run the draft on "
-                               "the five GEMV launches")
+        chain_gave_up = int(self.res_host[7]) & 0xffffffff
+        n_old = self.num_nodes
         self.last_accept, self.last_bonus = keep, bonus
         self.num_nodes = n_new
         self.draft_model.kv_cache.kv_offset = n_new
         self.target_model.kv_cache.kv_offset = n_new
+        if chain_gave_up:
+            self._chain_fallback(chain_gave_up, n_old, n_new)
         return eos == 0
+
+    def _chain_fallback(self, status, n_old, n_new):
+        """The draft's persistent chain gave up on a hand-off during this iteration (its launches need every workgroup
+        resident, i.e. the whole device).  The iteration's TOKENS are still right: a draft only proposes, the accept scan
+        keeps a proposal only where it equals the target's own sample, and the target never read anything the chain wrote.
+        What may be wrong is the draft's KV of the rows it processed.  So: take the chain out (the five GEMV launches are
+        bit-identical), drop the graph that has it captured, re-derive the draft KV of the committed rows, carry on."""
+        d = self.draft_model
+        if not getattr(self, "_chain_warned", False):
+            logger.warning(f"the draft model's persistent chain gave up on a hand-off (status {status:#x}: its launches need the "
+                           "whole device, one process per GPU); continuing on the five GEMV launches (UMB_CHAIN=0 selects them "
+                           "from the start)")
+            self._chain_warned = True
+        d.disable_chain()
+        self._graph = None
+        self.res[7:8].zero_()
+        lo = max(n_old - 1, 0)
+        if n_new > lo:
+            d.prefill_tokens(self.tokens[lo:n_new], lo, want_logits=False)
+            d.kv_cache.kv_offset = n_new
 
     @torch.inference_mode()
     def verify(self):
