@@ -303,18 +303,20 @@ def test_tp_two_ranks_share_one_gpu(dev, awq, allreduce):
     check_greedy(G, sd, PROMPT, a["static"], torch.float16, tol=0.12 if awq else None)
 
 
-def _rccl_graph_worker(q):
-    """body of test_tp_rccl_hook_inside_the_iteration_graph, in a process of its own: tearing down an RCCL communicator whose
-    collectives were captured into a hipGraph aborts the process now and then (inside gc / destroy_process_group, 2 of 8 runs) --
-    a teardown fault of the runtime stack, after every assertion has passed.  The verdict travels through the queue BEFORE the
-    teardown; the parent checks the verdict, not the exit code."""
+def _rccl_graph_worker(q, loops):
+    """body of test_tp_rccl_hook_inside_the_iteration_graph, in a process of its own (an abort inside the runtime stack must
+    fail ONE test, not the pytest run).  Round 5 met an abort in gc / destroy_process_group in 2 of 8 runs: the communicator
+    was destroyed while hipGraphs holding its collectives were alive.  Now the teardown is ordered
+    (tensor_parallel.shutdown_tensor_parallel: graphs -> drain -> peers -> group) and exercised `loops` times in this one
+    process -- init group, capture, replay, tear down -- and the process exits NORMALLY: the parent checks the exit code."""
+    import gc
     import traceback
     try:
         import torch.distributed as dist
         from hip_helpers import growmap, hip_model, static_engine
         from umbrella_amd.speculation.speculation_utils import IdTokenizer
         from umbrella_amd.speculation.static_speculation_engine import StaticSpeculationEngine
-        from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm
+        from umbrella_amd.tensor_parallel import TensorParallelLlama, TPComm, shutdown_tensor_parallel
         import __graft_entry__ as ge
         ge.build()
         dev = torch.device("cuda:0")
@@ -325,38 +327,43 @@ def _rccl_graph_worker(q):
             ref = ref_eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
         finally:
             os.environ.pop("UMB_SCHED")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        del ref_eng
         cfg = _cfg()
         sd = synth_state_small(cfg, G["seeds"]["target"])
-        for force in (True, False):
-            comm = TPComm()
-            assert comm.backend == "nccl" and not comm.staged
-            tp = TensorParallelLlama.build(cfg, sd, comm, 256, str(dev), dtype, force_hook=force)
-            calls = []
-            orig = comm.all_reduce
-            comm.all_reduce = lambda t, _o=orig: (calls.append(t.numel()), _o(t))[1]
-            draft, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, cuda_graph=True)
-            eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap=growmap("3x4"), max_length=256,
-                                          safe_buffer=16, stop_distance=8, draft_model_obj=draft, target_model_obj=tp,
-                                          tokenizer=IdTokenizer())
-            eng.initialize()
-            out = eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
-            assert out == ref
-            assert eng.use_graph and eng.graph_scope == "iteration" and eng._graph is not None
-            if force:       # hook calls happen at capture time only (prefill + warm-up + capture), replays issue none
-                n_iter = cfg.num_hidden_layers * 2
-                assert len(calls) > 0 and len(calls) % n_iter == 0
-                assert len(calls) < n_iter * 8, "the collectives are replayed from the graph, not re-issued per step"
-            else:
-                assert calls == []
+        for it in range(loops):
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(_free_port())
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            for force in ((True, False) if it == 0 else (True,)):
+                comm = TPComm()
+                assert comm.backend == "nccl" and not comm.staged
+                tp = TensorParallelLlama.build(cfg, sd, comm, 256, str(dev), dtype, force_hook=force)
+                calls = []
+                orig = comm.all_reduce
+                comm.all_reduce = lambda t, _o=orig: (calls.append(t.numel()), _o(t))[1]
+                draft, _ = hip_model(TCFG, G["seeds"]["target"], 256, dtype, dev, cuda_graph=True)
+                eng = StaticSpeculationEngine("d", "t", dtype=dtype, device=str(dev), growmap=growmap("3x4"), max_length=256,
+                                              safe_buffer=16, stop_distance=8, draft_model_obj=draft, target_model_obj=tp,
+                                              tokenizer=IdTokenizer())
+                eng.initialize()
+                out = eng.generate(input_ids=PROMPT, max_new_tokens=30)["generated_tokens"]
+                assert out == ref
+                assert eng.use_graph and eng.graph_scope == "iteration" and eng._graph is not None
+                if force:       # hook calls happen at capture time only (prefill + warm-up + capture), replays issue none
+                    n_iter = cfg.num_hidden_layers * 2
+                    assert len(calls) > 0 and len(calls) % n_iter == 0
+                    assert len(calls) < n_iter * 8, "the collectives are replayed from the graph, not re-issued per step"
+                else:
+                    assert calls == []
+                shutdown_tensor_parallel(tp, [eng], destroy_group=False)
+                del eng, tp, draft, comm
+                gc.collect()
+            shutdown_tensor_parallel(destroy_group=True)
         torch.cuda.synchronize()
         q.put("ok")
     except BaseException:
         q.put(traceback.format_exc())
     q.close()
-    q.join_thread()                                 # the verdict is in the pipe before the process goes
-    os._exit(0)                                     # no interpreter teardown: see the docstring
+    q.join_thread()
 
 
 @pytest.mark.gpu
@@ -364,19 +371,22 @@ def test_tp_rccl_hook_inside_the_iteration_graph(dev):
     """A 1-rank RCCL group with the all-reduce hook forced on (an all-reduce over one rank is the identity): every
     collective of the native layer chain goes through torch.distributed "nccl" on the launch stream and is captured
     into the iteration's hipGraph; tokens equal the plain single-GPU engine's bit for bit, and without the hook (the
-    real world-1 configuration) the path IS the plain one.  Runs in a spawned process (_rccl_graph_worker)."""
+    real world-1 configuration) the path IS the plain one.  Runs in a spawned process (_rccl_graph_worker) that repeats
+    init group -> capture -> replay -> ORDERED teardown several times and must exit with code 0."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_graph_worker, args=(q,))
+    loops = int(os.environ.get("UMB_RCCL_TEARDOWN_LOOPS", "6"))
+    p = ctx.Process(target=_rccl_graph_worker, args=(q, loops))
     p.start()
     try:
-        verdict = q.get(timeout=240)
+        verdict = q.get(timeout=600)
     finally:
-        p.join(timeout=30)
+        p.join(timeout=120)
         if p.is_alive():
             p.kill()
     assert verdict == "ok", verdict
+    assert p.exitcode == 0, f"the worker's teardown ended with exit code {p.exitcode} after {loops} init/capture/teardown rounds"
 
 
 class _ThreadComm:

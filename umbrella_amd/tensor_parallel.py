@@ -393,13 +393,24 @@ class TensorParallelLlama:
             raise
         self._raise_hook_error()
 
-    def close(self):
-        """unmap the peers' exchange buffers and free this rank's (call once the engines over this target are gone)"""
+    def close(self, engines=()):
+        """Ordered release.  A collective captured into a hipGraph keeps referring to its communicator's
+        resources: the graphs go FIRST, then the stream is drained, then the peers' exchange buffers are unmapped and this
+        rank's freed -- only after that may the caller destroy the process group (shutdown_tensor_parallel does all of it).
+        `engines`: every engine that ran over this target (their captured iteration graphs are dropped here)."""
+        import gc
+        for e in engines:
+            if getattr(e, "_graph", None) is not None:
+                e._graph = None
+        gc.collect()                                    # torch frees a CUDAGraph's exec on collection, not on rebinding
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if self.peer is not None:
             import ctypes as C
             self.m._tp.peer = C.POINTER(_lib.UmbTPPeer)()
             self.peer.close()
             self.peer = None
+        self._hook_cb = getattr(self, "_hook_cb", None)  # (the ctypes callback stays referenced while the model struct lives)
 
     def peer_self_check(self, rows: int = 13, tol: float = 0.02, rounds: int = 3) -> bool:
         """The direct peer all-reduce has only ever run with the ranks on ONE device (where every rank shares an L2); on a
@@ -592,6 +603,8 @@ def tp_measure(args, wl, dtype, device, rank, world):
               "iteration_in_one_hipgraph": bool(eng.use_graph and eng.graph_scope == "iteration"), "acc": acc,
               "parallelism": f"tp{world}: heads / MLP width / vocabulary split, 2 all-reduces of the [T, H] fp32 partial "
                              "sums per layer inside the native layer chain; draft replicated", "tree": "3x4", "scaling": "strong"})
+    # the measurement is done: graphs first, then the peers' buffers (the caller destroys the group afterwards)
+    shutdown_tensor_parallel(tgt if hasattr(tgt, "close") else None, [eng], destroy_group=False)
     return r
 
 
@@ -611,8 +624,31 @@ def run_tp_bench(args, wl, dtype, device, rank, world):
                "config": {"workload": wl["desc"], "parallelism": r["parallelism"], "tree": "3x4", "prompt_len": args.prompt_len},
                "accept_len": r["accept_len"], "value_raw_draft": r["tokens_per_s_raw_draft"], "tp": r}
         print(json.dumps(out), flush=True)
-    if dist.is_initialized():                                  # also the 1-rank group bench.py opens for the RCCL smoke run
-        if world > 1:
-            dist.barrier()
-        dist.destroy_process_group()
+    shutdown_tensor_parallel(destroy_group=True)               # also the 1-rank group bench.py opens for the RCCL smoke run
     return out
+
+
+def shutdown_tensor_parallel(target=None, engines=(), destroy_group: bool = True):
+    """Tear a tensor-parallel setup down in the one order that is safe with RCCL collectives captured in hipGraphs:
+    graphs -> stream drain -> peer buffers -> (barrier) -> process group.  Destroying the communicator while a live graph
+    still holds its kernels aborted the process now and then (round 5: 2 of 8 runs, worked around with os._exit)."""
+    import gc
+
+    import torch.distributed as dist
+    if target is not None:
+        target.close(engines)
+    else:
+        for e in engines:
+            if getattr(e, "_graph", None) is not None:
+                e._graph = None
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    if destroy_group and dist.is_available() and dist.is_initialized():
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        dist.destroy_process_group()
