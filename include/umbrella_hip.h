@@ -200,6 +200,12 @@ int umb_reduce_residual_norm(const void* partial, int S, int T, int N, const voi
 /* the same with xn_out in FM order (xn_fm_tt as fm_tt of umb_rmsnorm_fm; h_out stays row-major) */
 int umb_reduce_residual_norm_fm(const void* partial, int S, int T, int N, const void* residual, void* h_out,
                                 void* xn_out, const void* w, float eps, int xn_fm_tt, int dtype, umb_stream_t stream);
+/* the split-K reduce with the RMSNorm DEFERRED, N / 512 blocks per token row (round 6): h_out = round(round(sum_s partial) +
+ * residual); hw_out (may be NULL) = round(h * w), row-major or FM (hw_fm_tt as above); ssq_out[t][0 .. N/512) = the blocks' sums
+ * of h^2 -- the consumer applies rsqrt(sum ssq / N + eps) to its outputs (umb_gemm_fused ssq_in, umb_reduce_qkv_rope2).
+ * N % 512 == 0, ssq_stride >= N / 512.  Same reference lines as umb_reduce_residual_norm. */
+int umb_reduce_residual_hw(const void* partial, int S, int T, int N, const void* residual, void* h_out, void* hw_out,
+                           const void* w, float* ssq_out, int ssq_stride, int hw_fm_tt, int dtype, umb_stream_t stream);
 /* act = silu(gate) * up  (llama.py:107-110); partial rows are [gate | up] */
 int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, umb_stream_t stream);
 /* q/k/v split + apply_rotary_pos_emb (umbrella/models/model_utils.py:17-52) at positions pos[t]
@@ -245,6 +251,12 @@ int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, con
                    const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
                    int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
                    int ssq_stride, int dtype, umb_stream_t stream);
+/* the same with hw in FM order (hw_fm_tt token tiles, 0 = row-major).  The sums of squares keep their per-64-column grouping, so a
+ * token's 1 / rms is the same bits whether its forward carries 1 row or 64 (batch invariance of the deferred-norm schedule). */
+int umb_embed_prep_fm(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
+                      const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
+                      int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
+                      int ssq_stride, int hw_fm_tt, int dtype, umb_stream_t stream);
 
 /* ------------------------------------------------------------------ attention */
 /* flashinfer.single_prefill_with_kv_cache(custom_mask=...) (umbrella/attn/cache.py:77-85) and
@@ -363,7 +375,10 @@ typedef struct UmbWorkspace {
   uint32_t* counters;               /* >= max(N)/64 zeroed words for the split-K last-arriver epilogues */
   uint32_t* attn_counters;          /* >= Hkv * ceil(Tmax*(Hq/Hkv)/16) zeroed words */
   int32_t Tmax, attn_chunk, attn_splits, ssq_stride;
-  int32_t fused, pad_;              /* layer schedule: 0 = 8 launches (split-K reduced at kernel boundaries), 1 = 5 launches
+  int32_t fused, defer_norm;        /* defer_norm (schedule 0 only, no tensor parallelism, H % 512 == 0): the two residual reduces
+                                       run N / 512 blocks per row and leave hw = h * w_next + sums of squares; the consumers apply
+                                       1 / rms (umb_reduce_residual_hw).
+                                       layer schedule: 0 = 8 launches (split-K reduced at kernel boundaries), 1 = 5 launches
                                        (in-kernel last-arriver reduces; slower), 2 = low-latency 5 launches (whole-K
                                        workgroups, FM activations; T <= 64 only, wider forwards use schedule 0) */
   void* chain_xchg;                 /* NULL, or umb_chain_xchg_bytes(UMB_CHAIN_TMAX, H, I) bytes set up by

@@ -2,6 +2,8 @@
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -106,6 +108,96 @@ def test_reduce_residual_norm_and_silu(dev, dtype):
     gate, up = part.sum(0)[:, :I].to(dtype), part.sum(0)[:, I:].to(dtype)
     aref = torch.nn.functional.silu(gate) * up
     assert (act.cpu().float() - aref.float()).abs().max() <= 4 * torch.finfo(dtype).eps * aref.float().abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T", [1, 13, 31, 64])
+def test_deferred_norm_schedule_matches_the_in_place_one(dev, dtype, T):
+    """model.hip layer_split_defer (the default for <= 64-row forwards of split-schedule models with H % 512 == 0) against the
+    one-block-per-row reduce that normalises in place (UMB_DEFER_NORM=0), 3 layers of the 8B shape (H = 4096): logits agree to
+    16-bit rounding and pick the same arg-max on every row -- row-major operands (T < 16) and FM-ordered ones (16 .. 64)."""
+    import copy
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.models.llama import Llama
+    cfg = copy.copy(KNOWN["meta-llama/Llama-3.1-8B-Instruct"])
+    cfg.num_hidden_layers = 3
+    outs = []
+    for defer in ("1", "0"):
+        os.environ["UMB_DEFER_NORM"] = defer
+        try:
+            m = Llama("meta-llama/Llama-3.1-8B-Instruct", max_length=256, device=str(dev), dtype=dtype, config=cfg, sched="split", seed=2)
+            m.alloc()
+        finally:
+            os.environ.pop("UMB_DEFER_NORM", None)
+        assert m._ws.defer_norm == int(defer)
+        g = torch.Generator().manual_seed(T)
+        ids = torch.randint(3, 128000, (40 + T,), generator=g, dtype=torch.int32).to(dev)
+        m.prefill_tokens(ids[:40], 0)
+        pos = torch.arange(40, 40 + T, dtype=torch.int32, device=dev)
+        pre = torch.tensor([40], dtype=torch.int32, device=dev)
+        m.forward_explicit(ids[40:].contiguous(), pos, pos, pre, head_from=0)
+        torch.cuda.synchronize()
+        outs.append((m.logits_buffer[:T].clone(), m.hidden_buffer[:T].clone()))
+        del m
+    (la, ha), (lb, hb) = outs
+    assert torch.isfinite(la).all()
+    tol = (0.08 if dtype == torch.bfloat16 else 0.012) * float(lb.abs().max())
+    assert float((la - lb).abs().max()) <= tol, (float((la - lb).abs().max()), tol)
+    top2 = lb.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert torch.equal(la.argmax(-1)[clear], lb.argmax(-1)[clear])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,S,N", [(13, 4, 8192), (31, 8, 4096), (1, 2, 2048), (64, 17, 4096), (5, 1, 2048)])
+def test_reduce_residual_hw_many_blocks_per_row(dev, dtype, T, S, N):
+    """umb_reduce_residual_hw (round 6: the split schedule's residual reduce with the RMSNorm deferred, N / 512 blocks per row):
+    h is BIT-identical to umb_reduce_residual_norm's (same split order, same two roundings); hw = round(h * w) exactly, row-major
+    and in FM order; the N / 512 sums of squares add up to sum h^2 (fp32 order only); and what the consumer makes of them --
+    rsqrt(sum / N + eps) * (hw @ W) -- equals the GEMM over the normalised row (the reference's layer_norm then linear,
+    model_utils.py:54-64, llama.py:87-91) up to 16-bit rounding."""
+    from umbrella_amd import _lib
+    g = torch.Generator().manual_seed(T * 31 + S)
+    dt = _lib.dtype_code(dtype)
+    part = torch.randn(S, T, N, generator=g).to(dev)
+    res = torch.randn(T, N, generator=g).to(dtype).to(dev)
+    w = (1 + 0.1 * torch.randn(N, generator=g)).to(dtype).to(dev)
+    h0, x0 = torch.empty(T, N, dtype=dtype, device=dev), torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_residual_norm", part, S, T, N, res, h0, x0, w, 1e-5, dt)
+    G, stride = N // 512, 64
+    for fm in (0, _lib.load().umb_ll_token_tiles(T)):
+        h1 = torch.empty(T, N, dtype=dtype, device=dev)
+        hw = torch.zeros(max(fm * 16, T) * N, dtype=dtype, device=dev)
+        ssq = torch.full((T, stride), float("nan"), device=dev)
+        _lib.call("umb_reduce_residual_hw", part, S, T, N, res, h1, hw, w, ssq, stride, fm, dt)
+        torch.cuda.synchronize()
+        assert torch.equal(h1.view(torch.int16), h0.view(torch.int16))
+        if fm:
+            back = torch.empty(T, N, dtype=dtype, device=dev)
+            _lib.call("umb_from_fm", back, hw, T, N, dt)
+            hw_rm = back
+        else:
+            hw_rm = hw[:T * N].view(T, N)
+        want = (h0.float() * w.float()).to(dtype)
+        assert torch.equal(hw_rm.view(torch.int16), want.view(torch.int16))
+        assert torch.isnan(ssq[:, G:]).all() and torch.isfinite(ssq[:, :G]).all()          # exactly N / 512 groups written
+        tot = ssq[:, :G].double().sum(1)
+        ref = (h0.double() ** 2).sum(1)
+        assert ((tot - ref).abs() <= 1e-5 * ref).all()
+        per = (h0.float() ** 2).view(T, G, 512).sum(2)
+        assert ((ssq[:, :G] - per).abs() <= 1e-5 * per).all()
+        # the consumer's view: (1 / rms) (hw @ W^T) against (rmsnorm(h) * w) @ W^T
+        Wm = (torch.randn(64, N, generator=torch.Generator().manual_seed(3)) * 0.02).to(dev)
+        inv = torch.rsqrt(tot / N + 1e-5).float()
+        a = (hw_rm.float() @ Wm.T) * inv[:, None]
+        b = x0.float() @ Wm.T
+        assert (a - b).abs().max() <= 8 * torch.finfo(dtype).eps * b.abs().max()
+    # no hw / no ssq (a pipeline stage's last layer hands on h only)
+    h2 = torch.empty(T, N, dtype=dtype, device=dev)
+    _lib.call("umb_reduce_residual_hw", part, S, T, N, res, h2, None, None, None, 0, 0, dt)
+    assert torch.equal(h2.view(torch.int16), h0.view(torch.int16))
+    lib = _lib.load()
+    assert lib.umb_reduce_residual_hw(part.data_ptr(), S, T, 1000, res.data_ptr(), h2.data_ptr(), None, None, None, 0, 0, dt, None) != 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -50,7 +50,7 @@ class UmbWorkspace(C.Structure):
                 ("pos", C.c_void_p), ("slot", C.c_void_p), ("prefix", C.c_void_p), ("logits", C.c_void_p),
                 ("hw", C.c_void_p), ("ssq", C.c_void_p), ("counters", C.c_void_p), ("attn_counters", C.c_void_p),
                 ("Tmax", C.c_int32), ("attn_chunk", C.c_int32), ("attn_splits", C.c_int32), ("ssq_stride", C.c_int32),
-                ("fused", C.c_int32), ("pad_", C.c_int32), ("chain_xchg", C.c_void_p)]
+                ("fused", C.c_int32), ("defer_norm", C.c_int32), ("chain_xchg", C.c_void_p)]
 
 
 class UmbChain(C.Structure):
@@ -148,6 +148,7 @@ SIGNATURES = {
     "umb_rmsnorm_fm": [_P, _P, _P, _F, _I, _I, _I, _I, _P],
     "umb_reduce_residual_norm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P],
     "umb_reduce_residual_norm_fm": [_P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P],
+    "umb_reduce_residual_hw": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "umb_reduce_silu_mul": [_P, _I, _I, _I, _P, _I, _P],
     "umb_reduce_qkv_rope": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "umb_stream_read": [_P, C.c_size_t, _P, _P],
@@ -156,6 +157,7 @@ SIGNATURES = {
     "umb_h2d_layer": [_P, _P, C.c_size_t, _P, _P, _P],
     "umb_reduce_qkv_rope2": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _I, _P],
     "umb_embed_prep": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "umb_embed_prep_fm": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "umb_tree_attn": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "umb_argmax_rows": [_P, _P, _I, _I, _P],
     "umb_topk_rows": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -199,6 +199,52 @@ __global__ __launch_bounds__(256) void reduce_silu_mul_kernel(const float* __res
   *reinterpret_cast<uint2*>(act + (long)t * I + i) = pk;
 }
 
+// ---- split-K reduce + residual with the RMSNorm DEFERRED (round 6): many blocks per token row.
+// reduce_residual_norm_kernel above is one block per row because the norm needs the row's sum of squares: at T = 13 that is
+// 13 CUs each pulling S x N fp32 partials (128-256 KB at the 70B widths) at one CU's ~60-100 GB/s -- 2 of the launch's ~5.9 us.
+// Here a block owns 512 columns of one row: h <- round(round(sum_s partial) + h), hw <- round(h * w_next) (the next norm's
+// WEIGHT folded in, as the GEMM epilogue EPI_RESID and the low-latency schedule do), ssq[t][block] <- sum h^2 over its
+// columns; the consumer GEMM / q-k-v reduce applies 1/rms = rsqrt(sum_b ssq[t][b] / N + eps) to its outputs, where it
+// commutes with the matmul.  T x N/512 blocks, no cross-block step.  Reference: layer_norm + residual add,
+// umbrella/models/llama.py:95-96,112-113 and model_utils.py:54-64.
+template <typename P>
+__global__ __launch_bounds__(128) void reduce_residual_hw_kernel(const float* __restrict__ part, int S, int T, int N,
+                                                                 const u16* residual, u16* h_out, u16* __restrict__ hw_out,
+                                                                 const u16* __restrict__ w, float* __restrict__ ssq_out,
+                                                                 int ssq_stride, int hw_fm_tt) {
+  __shared__ float red[2];
+  const int b = blockIdx.x, t = blockIdx.y;
+  const int i = b * 512 + threadIdx.x * 4;
+  const long sstride = (long)T * N;
+  const float* p = part + (long)t * N + i;
+  f32x4 v[16];
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2) v[s2] = s2 < S ? LDP(p + (long)s2 * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint2 r = residual ? *reinterpret_cast<const uint2*>(residual + (long)t * N + i) : uint2{0u, 0u};
+  const uint2 g = hw_out ? *reinterpret_cast<const uint2*>(w + i) : uint2{0u, 0u};
+  f32x4 a = v[0];
+#pragma unroll
+  for (int s2 = 1; s2 < 16; ++s2)
+    if (s2 < S) a += v[s2];                                        // fixed order 0 .. S-1
+  for (int s2 = 16; s2 < S; ++s2) a += LDP(p + (long)s2 * sstride);
+  float x0 = rnd<P>(a[0]), x1 = rnd<P>(a[1]), x2 = rnd<P>(a[2]), x3 = rnd<P>(a[3]);
+  if (residual) { x0 += lo_f<P>(r.x); x1 += hi_f<P>(r.x); x2 += lo_f<P>(r.y); x3 += hi_f<P>(r.y); }
+  uint2 o;
+  o.x = pack2<P>(x0, x1); o.y = pack2<P>(x2, x3);
+  if (h_out) *reinterpret_cast<uint2*>(h_out + (long)t * N + i) = o;
+  x0 = lo_f<P>(o.x); x1 = hi_f<P>(o.x); x2 = lo_f<P>(o.y); x3 = hi_f<P>(o.y);
+  if (hw_out) {
+    uint2 ow;
+    ow.x = pack2<P>(x0 * lo_f<P>(g.x), x1 * hi_f<P>(g.x)); ow.y = pack2<P>(x2 * lo_f<P>(g.y), x3 * hi_f<P>(g.y));
+    *reinterpret_cast<uint2*>(hw_out + (hw_fm_tt ? fm_off(t, i, hw_fm_tt) : (long)t * N + i)) = ow;
+  }
+  if (!ssq_out) return;
+  float ss = wave_sum(x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) ssq_out[(long)t * ssq_stride + b] = red[0] + red[1];
+}
+
 // ---- QKV reduce + RoPE + KV append.  One block per (token, head) with D/2 active pairs.
 // partial row layout: [q (Hq*D) | k (Hkv*D) | v (Hkv*D)]
 // K cache / V^T cache: per kv head a slab of Lmax D / D (Lmax + UMB_VT_PAD) elements in MFMA fragment order (common.h kc_off / vt_off)
@@ -287,7 +333,7 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
                                                          const int* __restrict__ depth, int* __restrict__ pos_out,
                                                          int* __restrict__ slot_out, int* __restrict__ prefix_out,
                                                          u16* __restrict__ hw, const u16* __restrict__ norm_w,
-                                                         float* __restrict__ ssq, int ssq_stride) {
+                                                         float* __restrict__ ssq, int ssq_stride, int hw_fm_tt) {
   const int i = blockIdx.x;
   int tok, p, s, pre;
   if (tokens_all) {
@@ -313,7 +359,7 @@ __global__ __launch_bounds__(256) void embed_prep_kernel(u16* __restrict__ x, co
         o[e] = pack2<P>(a * lo_f<P>(w[e]), b * hi_f<P>(w[e]));
         sq += a * a + b * b;
       }
-      *reinterpret_cast<u32x4*>(hw + (long)i * H + k * 8) = o;
+      *reinterpret_cast<u32x4*>(hw + (hw_fm_tt ? fm_off(i, k * 8, hw_fm_tt) : (long)i * H + k * 8)) = o;
       sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);   // 8 threads = 64 columns
       if ((threadIdx.x & 7) == 0) ssq[(long)i * ssq_stride + (k >> 3)] = sq;
     }
@@ -405,6 +451,21 @@ extern "C" int umb_reduce_residual_norm(const void* partial, int S, int T, int N
   return umb_reduce_residual_norm_fm(partial, S, T, N, residual, h_out, xn_out, w, eps, 0, dtype, st);
 }
 
+// Many-blocks-per-row reduce with the norm deferred (reduce_residual_hw_kernel): h_out <- round(round(sum_s partial) + residual),
+// hw_out (may be NULL) <- round(h * w) row-major or FM (hw_fm_tt token tiles), ssq_out[t][0 .. N/512) <- per-block sums of h^2.
+extern "C" int umb_reduce_residual_hw(const void* partial, int S, int T, int N, const void* residual, void* h_out, void* hw_out,
+                                      const void* w, float* ssq_out, int ssq_stride, int hw_fm_tt, int dtype, hipStream_t st) {
+  if (N % 512 || T < 1 || S < 1 || hw_fm_tt < 0 || (hw_fm_tt && T > 16 * hw_fm_tt) || (hw_out && !w) ||
+      (ssq_out && ssq_stride < N / 512))
+    return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((reduce_residual_hw_kernel<P>), dim3(N / 512, T), dim3(128), 0, st, (const float*)partial, S, T, N,
+                       (const u16*)residual, (u16*)h_out, (u16*)hw_out, (const u16*)w, ssq_out, ssq_stride, hw_fm_tt);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
+
 extern "C" int umb_reduce_silu_mul(const void* partial, int S, int T, int I, void* act, int dtype, hipStream_t st) {
   if (I % 4) return UMB_EINVAL;
   const long n4 = (long)T * I / 4;
@@ -438,18 +499,26 @@ extern "C" int umb_reduce_qkv_rope(const void* partial, int S, int T, int Hq, in
                               bias, nullptr, 0, 0, 0.f, 0.f, dtype, st);
 }
 
+extern "C" int umb_embed_prep_fm(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
+                                 const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
+                                 int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
+                                 int ssq_stride, int hw_fm_tt, int dtype, hipStream_t st) {
+  if (H % 64 || T < 1 || (hw && (!norm_w || !ssq || ssq_stride < H / 64))) return UMB_EINVAL;
+  if (hw_fm_tt < 0 || (hw_fm_tt && (!hw || T > 16 * hw_fm_tt))) return UMB_EINVAL;
+  DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((embed_prep_kernel<P>), dim3(T), dim3(256), 0, st, (u16*)x, (const u16*)table, H, tok, pos, slot,
+                       prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out, (u16*)hw,
+                       (const u16*)norm_w, ssq, ssq_stride, hw_fm_tt);
+  })
+  UMB_LAUNCH_CHECK();
+  return UMB_OK;
+}
 extern "C" int umb_embed_prep(void* x, const void* table, int H, int T, const int* tok, const int* pos, const int* slot,
                               const int* prefix, const int* tokens_all, const int* n_ptr, int off, const int* depth,
                               int* pos_out, int* slot_out, int* prefix_out, void* hw, const void* norm_w, float* ssq,
                               int ssq_stride, int dtype, hipStream_t st) {
-  if (H % 64 || T < 1 || (hw && (!norm_w || !ssq || ssq_stride < H / 64))) return UMB_EINVAL;
-  DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((embed_prep_kernel<P>), dim3(T), dim3(256), 0, st, (u16*)x, (const u16*)table, H, tok, pos, slot,
-                       prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out, (u16*)hw,
-                       (const u16*)norm_w, ssq, ssq_stride);
-  })
-  UMB_LAUNCH_CHECK();
-  return UMB_OK;
+  return umb_embed_prep_fm(x, table, H, T, tok, pos, slot, prefix, tokens_all, n_ptr, off, depth, pos_out, slot_out, prefix_out,
+                           hw, norm_w, ssq, ssq_stride, 0, dtype, st);
 }
 
 extern "C" int umb_rope_inplace(void* q, void* k, const void* cosT, const void* sinT, const int* pos, int T, int Hq,

@@ -142,6 +142,69 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
   return UMB_OK;
 }
 
+// Schedule 0 with the RMSNorm deferred (ws->defer_norm; round 6): the same 8 launches, but the two residual reduces run N / 512
+// blocks per token row (umb_reduce_residual_hw: h, hw = h * w_next, sums of squares per block) instead of one block per row that
+// has to see the whole row before it can normalise -- at T = 13 thirteen CUs each pulled 128-256 KB of fp32 partials.  1 / rms is
+// applied where it commutes with the matmul: by the q/k/v reduce, by the gate/up epilogue, by the lm_head epilogue.  *groups:
+// how many sums of squares per token the producer of ws->hw left (H / 64 after the embedding kernel, H / 512
+// after a residual reduce).
+// Forwards of <= 64 rows only: from 65 rows on the one-block-per-row reduce already fills the chip and the wide GEMMs do not
+// want a per-token factor in their epilogues (C3 / C4 iterations measured 1 % slower with it; the two regimes differ in their
+// int4 arithmetic anyway, so no invariance is lost across that boundary).
+static inline bool use_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbTP* tp) {
+  return s->T <= 64 && ws->fused == 0 && ws->defer_norm && !tp_on(tp) && m->H % 512 == 0 && ws->ssq_stride >= m->H / 64 && ws->ssq_stride % 4 == 0 &&
+         (m->H / 512) % 4 == 0;
+}
+static int prologue_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, int fm, int* groups,
+                          hipStream_t st) {
+  if (s->T < 1 || s->T > ws->Tmax) return UMB_EINVAL;
+  // one grouping of the sums of squares (per 64 columns) whatever the row count and the layout of hw: a token's 1 / rms is the
+  // same bits in a 1-row and in a 64-row forward
+  *groups = m->H / 64;
+  return umb_embed_prep_fm(ws->h, s->skip_embed ? nullptr : m->embed, m->H, s->T, s->tokens, s->positions, s->slots,
+                           s->prefix_len, s->tokens_all, s->n_ptr, s->tree_off, s->depth, ws->pos, ws->slot, ws->prefix,
+                           ws->hw, first_norm, ws->ssq, ws->ssq_stride, fm, m->dtype, st);
+}
+static int layer_split_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
+                             const void* next_norm, int* groups, hipStream_t st, int fm, bool more) {
+  const int T = s->T, dt = m->dtype;
+  const size_t esz = 2;
+  char* kc = (char*)m->k_cache + (size_t)l * m->Hkv * m->Lmax * m->D * esz;
+  char* vt = (char*)m->vt_cache + (size_t)l * m->Hkv * VT_LD(m->Lmax) * m->D * esz;
+  UmbGemmFused fxm = {}, fgu = {};
+  fxm.pad1 = 1;                                             // x in FM order
+  const UmbGemmFused* xf = fm ? &fxm : nullptr;
+  CK(lin(ly.qkv, ws->hw, m->H, ws->partial, T, dt, st, 0, xf));
+  CK(umb_reduce_qkv_rope2(ws->partial, eff_s(ly.qkv, T), T, m->Hq, m->Hkv, m->D, m->Lmax, ws->pos, ws->slot, m->rope_cos,
+                          m->rope_sin, ws->q, kc, vt, /*paired=*/1, ly.qkv_bias, ws->ssq, *groups, ws->ssq_stride, (float)m->H,
+                          m->eps, dt, st));
+  CK(umb_tree_attn2(ws->attn, ws->q, kc, vt, ws->attn_po, ws->attn_ml, ws->prefix, s->mask_bits, s->mask_words,
+                    s->n_mask_keys, T, m->Hq, m->Hkv, m->D, m->Lmax, ws->attn_chunk, ws->attn_splits, m->attn_scale,
+                    ws->attn_counters, fm, dt, st));
+  CK(lin(ly.o, ws->attn, m->Hq * m->D, ws->partial, T, dt, st, 0, xf, true));
+  const int g2 = m->H / 512;
+  CK(umb_reduce_residual_hw(ws->partial, eff_s(ly.o, T, true), T, m->H, ws->h, ws->h, ws->hw, ly.norm2, ws->ssq, ws->ssq_stride, fm,
+                            dt, st));
+  if (ly.gu.S != 1) return UMB_EINVAL;     // gate/up rows are interleaved at load time: SiLU(gate)*up is the epilogue
+  fgu.ssq_in = ws->ssq; fgu.ssq_groups = g2; fgu.pad0 = ws->ssq_stride; fgu.ssq_dim = (float)m->H; fgu.eps = m->eps;
+  fgu.pad1 = fm ? 3 : 0;                                    // x and the SiLU output in FM order
+  CK(lin(ly.gu, ws->hw, m->H, ws->act, T, dt, st, /*EPI_SILU*/2, &fgu));
+  CK(lin(ly.down, ws->act, m->I, ws->partial, T, dt, st, 0, xf, true));
+  CK(umb_reduce_residual_hw(ws->partial, eff_s(ly.down, T, true), T, m->H, ws->h, ws->h, next_norm ? ws->hw : nullptr, next_norm,
+                            next_norm ? ws->ssq : nullptr, ws->ssq_stride, more ? fm : 0, dt, st));
+  *groups = g2;
+  return UMB_OK;
+}
+static int head_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, int groups, hipStream_t st) {
+  if (s->head_from >= s->T) return UMB_OK;
+  const int rows = s->T - s->head_from;
+  const char* x = (const char*)ws->hw + (size_t)s->head_from * m->H * 2;
+  UmbGemmFused fh = {};
+  fh.ssq_in = ws->ssq + (size_t)s->head_from * ws->ssq_stride; fh.ssq_groups = groups; fh.pad0 = ws->ssq_stride;
+  fh.ssq_dim = (float)m->H; fh.eps = m->eps;
+  return lin(m->lm_head, x, m->H, ws->logits, rows, m->dtype, st, /*EPI_ROUND*/1, &fh);
+}
+
 // Schedule 1: one decoder layer = 5 launches.  RMSNorm is split: its weight is folded into the activations by
 // the producer (hw = h * w), its per-token factor is applied to the consumer GEMM's outputs from `ssq`.
 static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbLayer& ly, int l,
@@ -460,13 +523,17 @@ static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbSte
   }
   const bool ll = use_ll(ws, s);
   const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
+  const bool df = !ll && use_defer(m, ws, s, nullptr);
   int sg = 4;
-  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st)
+        : df ? prologue_defer(m, ws, s, m->layers[lb].norm1, fm, &sg, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
   for (int l = lb; l < le; ++l) {
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(ll ? layer_ll(m, ws, s, m->layers[l], l, nn, &sg, st) : layer(m, ws, s, m->layers[l], l, nn, st, fm, l + 1 < le));
+    CK(ll ? layer_ll(m, ws, s, m->layers[l], l, nn, &sg, st)
+          : df ? layer_split_defer(m, ws, s, m->layers[l], l, nn, &sg, st, fm, l + 1 < le)
+               : layer(m, ws, s, m->layers[l], l, nn, st, fm, l + 1 < le));
   }
-  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
+  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : df ? head_defer(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
 }
 
@@ -538,8 +605,10 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
 
   const bool ll = use_ll(ws, s);
   const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
+  const bool df = !ll && use_defer(m, ws, s, nullptr);
   int sg = 4;
-  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
+  CK(ll ? prologue_ll(m, ws, s, m->layers[lb].norm1, st)
+        : df ? prologue_defer(m, ws, s, m->layers[lb].norm1, fm, &sg, st) : prologue(m, ws, s, m->layers[lb].norm1, st, fm));
   for (int l = lb; l < le; ++l) {
     UmbLayer cur = m->layers[l];
     int buf = -1;
@@ -549,7 +618,8 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       cur = rebase(m->layers[l], off->dev_slab[buf]);
     }
     const void* nn = (l + 1 < le) ? m->layers[l + 1].norm1 : (le == m->L ? m->final_norm : nullptr);
-    CK(ll ? layer_ll(m, ws, s, cur, l, nn, &sg, st) : layer(m, ws, s, cur, l, nn, st, fm, l + 1 < le));
+    CK(ll ? layer_ll(m, ws, s, cur, l, nn, &sg, st)
+          : df ? layer_split_defer(m, ws, s, cur, l, nn, &sg, st, fm, l + 1 < le) : layer(m, ws, s, cur, l, nn, st, fm, l + 1 < le));
     if (buf >= 0) {
       ++used;
       if (hipEventRecord((hipEvent_t)off->ev_free[buf], st) != hipSuccess) return UMB_EHIP;
@@ -571,7 +641,7 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
       for (int i = 0; i < nfirst; ++i) CK(issue_copy(first[i], i));
     for (int i = 0; i < NS; ++i) pf[i] = first[i];
   }
-  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : head(m, ws, s, st));
+  if (le == m->L) CK(ll ? head_ll(m, ws, s, sg, st) : df ? head_defer(m, ws, s, sg, st) : head(m, ws, s, st));
   return UMB_OK;
 }
 

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void vgemm_w_kernel(const u32x4* __restrict__ 
     if (tok >= tend) continue;
     float inv = 1.f;
     if (fx.ssq_in) {
-      const float* sq = fx.ssq_in + (long)tok * fx.ssq_groups;
+      const float* sq = fx.ssq_in + (long)tok * (fx.ssq_stride ? fx.ssq_stride : fx.ssq_groups);
       float a = 0.f;
       for (int q = 0; q < fx.ssq_groups; q += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sq + q); a += v[0]; a += v[1]; a += v[2]; a += v[3]; }
       inv = rsqrtf(a / fx.ssq_dim + fx.eps);

@@ -601,6 +601,9 @@ class Llama(LLMBase):
         ws.counters, ws.attn_counters = self._counters.data_ptr(), self._attn_counters.data_ptr()
         ws.Tmax, ws.attn_chunk, ws.attn_splits, ws.ssq_stride = T, self.attn_chunk, self.attn_splits, self.ssq_stride
         ws.fused = 2 if (self.sched == "ll" and not self.fused) else int(self.fused)
+        # schedule 0 with the RMSNorm deferred (model.hip layer_split_defer): many-blocks-per-row residual reduces; UMB_DEFER_NORM=0:
+        # the one-block-per-row reduce that normalises in place (A/B; tensor-parallel shards always take that one)
+        ws.defer_norm = int(ws.fused == 0 and os.environ.get("UMB_DEFER_NORM", "1") != "0")
         if getattr(self, "chain", False):
             self._chain_setup()
 
