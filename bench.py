@@ -560,18 +560,29 @@ def secondary_configs(device, seed=0):
             eng = AutoEngine.from_config(device, engine="dynamic", model=T70, draft_model=D1B, dtype=torch.float16, width=16,
                                          num_beams=24, depth=16, max_length=4096, offload=True, num_cache_layers=ncl, seed=seed)
             eng.initialize()
-            # per-step times after two warm steps, median of three (all three are reported)
+            # STEADY STATE, as generation runs it: step() ends with a synchronize of the LAUNCH stream only (the accept result), so
+            # the next verify's first slabs keep crossing the link while the host decides and the next draft tree runs.  Rounds
+            # 2-5 timed every step between two DEVICE-wide synchronizes, which also drain the copy stream: each timed step then
+            # began with a full slab ring and an idle link for the whole draft + resident-prefix phase (~36 ms at 40 resident
+            # layers) -- 356 ms per step where the link's 40 back-to-back copies take 318 (profiles/r06_offload_copy_profile.txt).
+            # Both figures are reported; `ms_per_step` is the steady one over 5 consecutive steps, one clock around them.
             assert eng._prefill(prompt)
             for _ in range(2):
                 eng.step()
+            start = eng.num_nodes
+            t0 = time.time()
+            nst = 5
+            for _ in range(nst):
+                eng.step()                              # (ends with current_stream().synchronize(): the step's tokens are final)
+            ms = (time.time() - t0) * 1e3 / nst
+            acc = (eng.num_nodes - start) / nst
             torch.cuda.synchronize()
-            times, start = [], eng.num_nodes
-            for _ in range(3):
+            times = []
+            for _ in range(3):                          # the old way, for continuity: every step between device-wide synchronizes
                 t0 = time.time()
                 eng.step()
                 torch.cuda.synchronize()
                 times.append((time.time() - t0) * 1e3)
-            ms, acc = sorted(times)[1], (eng.num_nodes - start) / 3
             m = eng.target_model
             streamed = sum(1 for h in m.host_slabs if h is not None) * m.slab_bytes
             torch.cuda.synchronize()
@@ -580,7 +591,7 @@ def secondary_configs(device, seed=0):
                               "w16/b24/d16 (T=257)", "ms_per_step": round(ms, 1), "accept_len_raw_draft": round(acc, 2),
                     "streamed_GB_per_verify": round(streamed / 1e9, 2), "bound": "host link (PCIe Gen5 x16, 63 GB/s spec)",
                     "achieved_GBs": round(streamed / ms / 1e6, 1), "frac": round(streamed / ms / 1e6 / 63.0, 4),
-                    "step_ms": [round(t, 1) for t in times], "host": place}
+                    "steady_steps": nst, "step_ms_device_synced": [round(t, 1) for t in times], "host": place}
         return run
 
     guarded("c2", c2)
@@ -590,11 +601,9 @@ def secondary_configs(device, seed=0):
     shared.clear()
     torch.cuda.empty_cache()
     def fresh_host():
-        # Every offload configuration pins fresh host memory, as a process running it alone does (torch caches pinned blocks).  The
-        # 40-resident-layer figure still varies with the process's history on the host side -- 330 ms per step stand-alone
-        # (scripts/bench_configs.py), 332 / 357 / 377 inside this script on the same build depending on the headline's length and
-        # the box, each steady over its steps (`step_ms`) -- while the all-streamed one does not (647-656): pinned-page placement
-        # relative to the GPU's socket is the suspect; the link, not a kernel, is what moves.
+        # Every offload configuration pins fresh host memory, as a process running it alone does (torch caches pinned blocks).
+        # (Rounds 3-5 chased a 330 / 357 / 377 ms spread of the 40-resident-layer figure through NUMA placement; it was the
+        # per-step device-wide synchronize of this script -- see c3_offload.)
         import gc
         gc.collect()
         torch.cuda.empty_cache()
