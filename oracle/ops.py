@@ -27,6 +27,36 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
 # umbrella/models/model_utils.py:17-52 (HF rotate-half, arbitrary position_ids)
 # ----------------------------------------------------------------------------
 
+def rope_inv_freq(head_dim: int, rope_theta: float, rope_scaling: dict | None = None):
+    """(inv_freq [D/2] fp32, attention_scaling).  The reference reads both off the HF model
+    (``hf_model.model.rotary_emb.inv_freq`` / ``.attention_scaling``, umbrella/models/llama.py:48-49, 57-58); this is HF's
+    published initialiser restated on its own (numpy, float64 until the last step) -- the ORACLE's copy: tests build the
+    oracle model from this one and the product from umbrella_amd.models.config.rope_inv_freq, so a slip in either shows up
+    as a parity failure instead of cancelling out.  Pinned to the reference by tests/golden/model_logits.npz `inv_freq`
+    (recorded from the HF module, tests/test_oracle_golden.py).  default: theta^(-2i/D); "llama3": wavelengths beyond
+    original_max / low_freq_factor are divided by `factor`, those below original_max / high_freq_factor kept, the band
+    between interpolated linearly in original_max / wavelength."""
+    D = int(head_dim)
+    inv = 1.0 / np.power(float(rope_theta), np.arange(0, D, 2, dtype=np.float64) / D)
+    inv = inv.astype(np.float32).astype(np.float64)           # HF builds the default frequencies in fp32 first
+    rs = rope_scaling or {}
+    if rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi = float(rs["factor"]), float(rs["low_freq_factor"]), float(rs["high_freq_factor"])
+        old = float(rs["original_max_position_embeddings"])
+        out = np.empty_like(inv)
+        for i, f in enumerate(inv):
+            wl = 2.0 * math.pi / f
+            if wl < old / hi:
+                out[i] = f
+            elif wl > old / lo:
+                out[i] = f / factor
+            else:
+                t = (old / wl - lo) / (hi - lo)
+                out[i] = (1.0 - t) * f / factor + t * f
+        inv = out
+    return torch.from_numpy(inv.astype(np.float32)), 1.0
+
+
 def rope_cache(inv_freq: torch.Tensor, attention_scaling: float, max_length: int, dtype):
     pos = torch.arange(max_length, dtype=torch.float32)
     freqs = torch.outer(pos, inv_freq.float())              # [Lmax, D/2]

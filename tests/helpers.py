@@ -5,9 +5,10 @@ import os
 import numpy as np
 import torch
 
+from oracle import ops as _oracle_ops
 from oracle.engine import OracleDynamicEngine, OracleStaticEngine
 from oracle.model import OracleLlama
-from umbrella_amd.models.config import LlamaCfg, rope_inv_freq
+from umbrella_amd.models.config import LlamaCfg
 from umbrella_amd.models.synthetic import synth_state_small
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -25,7 +26,8 @@ def tiny_cfg(d: dict) -> LlamaCfg:
 def oracle_model(cfgd, seed, max_length, dtype=torch.float32, slot_cache=False, exit_layer=-1, state=None):
     cfg = tiny_cfg(cfgd)
     sd = state if state is not None else synth_state_small(cfg, seed)
-    inv, scale = rope_inv_freq(cfg)
+    # the oracle's OWN frequency table (oracle/ops.py rope_inv_freq), not the product's: see its docstring
+    inv, scale = _oracle_ops.rope_inv_freq(cfg.head_dim, cfg.rope_theta, cfg.rope_scaling)
     return OracleLlama(cfg, sd, inv, scale, max_length=max_length, dtype=dtype, slot_cache=slot_cache,
                        exit_layer=exit_layer)
 

@@ -202,8 +202,13 @@ def test_engines_replay_reference_token_sequences(dev, case_name):
     got = out["generated_tokens"]
     margins, _ = _margins(sd, case["prompt"] + gold, len(case["prompt"]),
                           first_eos_mask=case["eos"] if c["engine"] == "dynamic" else None)
-    # identical sequence (an EOS-terminated case stops at the same place) unless a margin-flagged near-tie is found
-    _require_full_or_flagged(got, gold, margins, TOL[dtype])
+    # identical sequence (an EOS-terminated case stops at the same place) unless a margin-flagged near-tie is found -- and a
+    # near-tie exit is only accepted after at least 8 tokens (or the whole recorded sequence, if shorter) have matched: a replay
+    # that leaves the record at token 0 says nothing.  How far every case got is reported with the run's parity facts.
+    from conftest import report_fact
+    same, diverged = _require_full_or_flagged(got, gold, margins, TOL[dtype])
+    report_fact(f"reference greedy replay/{case_name}", {"tokens_matched": same, "recorded": len(gold), "near_tie_exit": diverged})
+    assert same >= min(8, len(gold)), (same, len(gold))
 
 
 def test_static_two_turn_trace_replay(dev):

@@ -28,11 +28,24 @@ def test_rope_matches_reference():
 
 
 def test_rope_tables_match_hf_inv_freq():
-    from umbrella_amd.models.config import LlamaCfg, rope_inv_freq
-    inv, scale = rope_inv_freq(LlamaCfg(**G["target_cfg"]))
+    """Both frequency tables -- the product's (models/config.py) and the oracle's own (oracle/ops.py; what tests/helpers.py
+    builds the oracle model from) -- against the values recorded from HF's rotary module, and against each other on the
+    real configurations incl. the llama3 frequency scaling of the 1B / 8B / 70B models."""
+    from umbrella_amd.models.config import KNOWN, LlamaCfg, rope_inv_freq
+    cfg = LlamaCfg(**G["target_cfg"])
     ml = np.load(os.path.join(GOLD, "model_logits.npz"))
-    assert scale == 1.0
+    inv, scale = rope_inv_freq(cfg)
+    oinv, oscale = ops.rope_inv_freq(cfg.head_dim, cfg.rope_theta, cfg.rope_scaling)
+    assert scale == 1.0 and oscale == 1.0
     np.testing.assert_allclose(inv.numpy(), ml["inv_freq"], rtol=1e-6)
+    np.testing.assert_allclose(oinv.numpy(), ml["inv_freq"], rtol=1e-6)
+    for name in ("meta-llama/Llama-3.2-1B-Instruct", "meta-llama/Llama-3.1-8B-Instruct",
+                 "hugging-quants/Meta-Llama-3.1-70B-Instruct-AWQ-INT4"):
+        c = KNOWN[name]
+        a, _ = rope_inv_freq(c)
+        b, _ = ops.rope_inv_freq(c.head_dim, c.rope_theta, c.rope_scaling)
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-6)
+        assert c.rope_scaling and float(a[-1]) < float(a[0])
 
 
 def test_masked_attention_matches_reference_static_cache():
