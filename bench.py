@@ -864,6 +864,24 @@ def main():
             out["context_sweep"] = context_sweep(eng, wl, gm, acc, args)
         del eng
         torch.cuda.empty_cache()
+        if not args.no_secondary and args.workload == "70b-awq+1b" and not args.tree:
+            # a labelled SECOND line next to the headline, never the headline itself: the same workload, acceptance vector, seed,
+            # steps and timing method on the growmap re-tuned for MI355X cost ratios (umbrella_amd/trees/mi355x_70b_awq_1b-T16d3.json,
+            # scripts/tune_growmap.py: 15 nodes of depth <= 3 -- one draft forward fewer, a full 16-row verify tile)
+            try:
+                wl2 = dict(wl, tree="mi355x-T16d3", desc=wl["desc"] + " [growmap: mi355x-T16d3]")
+                e2, gm2, acc2, dt2, tok2, info2 = headline(args, wl2, dtype, device, rank, world, dist, agg_device)
+                l2 = headline_line(args, wl2, e2, gm2, acc2, dt2, tok2, info2, world)
+                out["tuned_tree_line"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "accept_len", "value_raw_draft",
+                                                              "draft_forwards_per_iter", "iter_bytes_GB", "iter_hbm_frac")}
+                out["tuned_tree_line"].update({"tree": "mi355x-T16d3", "tree_size": e2.tree_size,
+                                               "vs_headline_tokens_per_s": round(l2["value"] / out["value"], 4),
+                                               "note": "same acceptance vector and seed as the headline; the headline stays on "
+                                                       "the reference's 3x4 tree"})
+                del e2
+            except Exception as e:
+                out["tuned_tree_line"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
         if not args.no_secondary and args.workload == "70b-awq+1b":
             out["secondary"] = secondary_configs(device, args.seed)
         if not args.no_cpu_baseline and args.workload != "tiny":          # the CPU leg runs on rank 0 at N = 1 only
