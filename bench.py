@@ -948,6 +948,8 @@ def main():
     gc.collect()
     if not args.dry_run:
         torch.cuda.synchronize()
+    if os.environ.get("UMB_BENCH_HARD_EXIT") == "1":      # escape hatch only (default off): leave without tearing RCCL down
+        os._exit(0)
     dist.destroy_process_group()
     return out
 

@@ -1,19 +1,16 @@
 #!/bin/bash
-# Experiment libraries: build/variants/lib_<name>.so from the in-tree sources with extra / replaced hipcc flags.
-#   bash scripts/build_variant.sh <name> "<extra -D / -mllvm flags>" [novgpr]
-# Only gemm.hip is recompiled per variant (the other objects are cached in build/obj); select at run time with
-# UMB_LIB_PATH=build/variants/lib_<name>.so (experiments only: the product always loads umbrella_amd/csrc/libumbrella_hip.so).
+# Experiment libraries: build/variants/lib_<name>.so = the in-tree objects (umbrella_amd/csrc/build, written by
+# __graft_entry__.build()) with ONE source recompiled under extra / replaced hipcc flags.
+#   bash scripts/build_variant.sh <name> "<extra -D / -mllvm flags>" [source.hip (default gemm.hip)] [novgpr]
+# Select at run time with UMB_LIB_PATH=build/variants/lib_<name>.so (experiments only: the product always loads
+# umbrella_amd/csrc/libumbrella_hip.so).  scripts/r6/build_vgw_variant.sh is the same for vgemm.hip.
 root=$(cd "$(dirname "$0")/.." && pwd)
-name=$1; extra=$2; mode=$3
-src=$root/umbrella_amd/csrc; obj=$root/build/obj; mkdir -p "$obj" "$root/build/variants"
-base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=16"
-vg="-mllvm -amdgpu-mfma-vgpr-form=1"
-for f in lowlat gemv epilogue attn sample tp model; do
-  if [ ! -f "$obj/$f.o" ] || [ "$src/$f.hip" -nt "$obj/$f.o" ] || [ "$src/common.h" -nt "$obj/$f.o" ]; then
-    /opt/rocm/bin/hipcc $base $vg -c "$src/$f.hip" -o "$obj/$f.o" &
-  fi
-done
-g=$vg; [ "$mode" = novgpr ] && g=""
-/opt/rocm/bin/hipcc $base $g $extra -c "$src/gemm.hip" -o "$obj/gemm_$name.o" &
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$obj"/{lowlat,gemv,epilogue,attn,sample,tp,model}.o "$obj/gemm_$name.o" -o "$root/build/variants/lib_$name.so" && echo "built build/variants/lib_$name.so"
+name=$1; extra=$2; srcf=${3:-gemm.hip}; mode=$4
+src=$root/umbrella_amd/csrc; mkdir -p "$root/build/variants" "$root/build/obj"
+python -c "import sys; sys.path.insert(0, '$root'); import __graft_entry__ as g; g.build()" > /dev/null 2>&1
+vg="-mllvm -amdgpu-mfma-vgpr-form=1"; [ "$mode" = novgpr ] && vg=""
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $vg -mllvm -amdgpu-kernarg-preload-count=16 $extra \
+  -c "$src/$srcf" -o "$root/build/obj/${srcf%.hip}_$name.o" || exit 1
+objs=$(ls "$src"/build/*.o | grep -v "/$srcf\.")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$root/build/obj/${srcf%.hip}_$name.o" -o "$root/build/variants/lib_$name.so" \
+  && echo "built build/variants/lib_$name.so"
