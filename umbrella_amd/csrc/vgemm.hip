@@ -341,17 +341,34 @@ static inline int vgw_ver() {
   static const int v = getenv("UMB_VGW") ? atoi(getenv("UMB_VGW")) : 1;
   return v;
 }
-static inline void vgw_shape(int T, int* nchunk, int* tt) {
+// The chunk count also sets how well the grid of (N / 256) x nchunk x S workgroups fills the 256 CUs (one workgroup per CU): one
+// chunk more than the minimum is taken when it turns a ragged last round into whole rounds (T = 769, o / down at S = 2:
+// 32 x 3 x 2 = 192 workgroups = 75 % of the chip, 32 x 4 x 2 = 256 = all of it), at the price of one more pass over the weights
+// and shorter dequant amortisation (UMB_VGW_FILL=0: always the minimum).  A function of (T, N, S) only.
+static inline void vgw_shape(int T, int N, int S, int* nchunk, int* tt) {
   const int NT = (T + 15) / 16;
-  int nc = (NT + 17) / 18;
-  *nchunk = nc;
-  *tt = (NT + nc - 1) / nc;
+  const int nc0 = (NT + 17) / 18;
+  static const bool fill = getenv("UMB_VGW_FILL") == nullptr || atoi(getenv("UMB_VGW_FILL")) != 0;
+  int best = nc0;
+  if (fill) {
+    double best_cost = 1e30;
+    for (int nc = nc0; nc <= nc0 + 1 && nc <= NT; ++nc) {
+      const long wgs = (long)(N / 256) * nc * S;
+      const long rounds = (wgs + 255) / 256;
+      const int ttc = (NT + nc - 1) / nc;
+      // time ~ rounds x (tiles per chunk + a fixed per-workgroup cost worth ~1.5 tiles: prologue, epilogue, weight re-read)
+      const double cost = (double)rounds * (ttc + 1.5);
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = nc; }
+    }
+  }
+  *nchunk = best;
+  *tt = (NT + best - 1) / best;
 }
 
 extern "C" int umb_vgemm_w_ok(int T, int N, int K, int S, int epi) {
   if (vgw_ver() == 0 || T <= 64 || N % 256 || K % 128 || epi > EPI_SILU || S < 1 || S > K / 128) return 0;
   int nc, tt;
-  vgw_shape(T, &nc, &tt);
+  vgw_shape(T, N, S, &nc, &tt);
   if (tt < 5) return 0;
   return (N / 256) * nc * S >= 128;                // small layers keep the finer-grained kernels of gemm.hip
 }
@@ -379,7 +396,7 @@ static int vgw_launch(const void* wp, const void* meta, const u16* x, int ldx, f
 int umb_vgemm_w(const void* wp, const void* meta, const u16* x, int ldx, float* out, int T, int N, int K, int S, int epi,
                 const GemmFused& fx, hipStream_t st) {
   int nc, tt;
-  vgw_shape(T, &nc, &tt);
+  vgw_shape(T, N, S, &nc, &tt);
   switch (tt) {
 #define VGW_CASE(n) case n: return vgw_launch<n>(wp, meta, x, ldx, out, T, N, K, S, epi, nc, fx, st)
     VGW_CASE(5); VGW_CASE(6); VGW_CASE(7); VGW_CASE(8); VGW_CASE(9); VGW_CASE(10); VGW_CASE(11); VGW_CASE(12); VGW_CASE(13);
