@@ -169,6 +169,32 @@ def test_engine_falls_back_to_gemv_launches_and_emits_the_same_tokens(dev):
     assert e.draft_model.chain and e.draft_model.chain_status() == 0
 
 
+@pytest.mark.parametrize("T", [16, 32])
+def test_draft_role_leaves_the_low_latency_schedule_from_16_rows(dev, T):
+    """model.hip use_ll: a DRAFT-role model (row-major weight copies published by use_gemv) runs its 16+-row forwards on the split
+    schedule with FM operands and the deferred norm (measured faster: 0.843 / 0.915 ms vs 0.889 / 1.099 at 16 / 32 rows), a model
+    without the role stays on the low-latency schedule.  Same weights, two schedules: logits agree to 16-bit rounding, every clear
+    row picks the same arg-max, and both caches hold the same keys up to rounding."""
+    dtype = torch.float16
+    a = _draft(dev, dtype, 4, False)                    # draft role (GEMV copies), chain off: irrelevant at these row counts
+    from umbrella_amd.models.config import KNOWN
+    from umbrella_amd.models.llama import Llama
+    cfg = copy.copy(KNOWN["meta-llama/Llama-3.2-1B-Instruct"])
+    cfg.num_hidden_layers = 4
+    b = Llama("meta-llama/Llama-3.2-1B-Instruct", max_length=256, device=dev, dtype=dtype, config=cfg, seed=0)
+    b.alloc()                                            # no use_gemv: low-latency schedule at every <= 64-row forward
+    assert a.sched == "ll" and b.sched == "ll" and a.gemv and not getattr(b, "gemv", False)
+    la, ha, ka, _ = _step(a, dev, T)
+    lb, hb, kb, _ = _step(b, dev, T)
+    assert torch.isfinite(la).all() and not torch.equal(la, lb)          # two schedules, two summation orders
+    tol = 0.012 * float(lb.abs().max())
+    assert float((la - lb).abs().max()) <= tol
+    top2 = lb.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert torch.equal(la.argmax(-1)[clear], lb.argmax(-1)[clear]) and int(clear.sum()) >= T // 2
+    assert float((ka.float() - kb.float()).abs().max()) <= 0.02 * float(kb.float().abs().max())
+
+
 def test_chain_rejects_what_it_does_not_cover(dev):
     from umbrella_amd import _lib
     lib = _lib.load()

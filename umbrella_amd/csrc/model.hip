@@ -91,7 +91,7 @@ static inline int split_fm_tt(const UmbModel* m, const UmbWorkspace* ws, const U
   static const bool off = getenv("UMB_SPLIT_FM") != nullptr && getenv("UMB_SPLIT_FM")[0] == '0';
   // from 16 rows: whole forwards, FM vs row-major -- 8B-AWQ 16 / 32 rows 2.006 -> 1.969 / 2.475 -> 2.414 ms, 8B dense 31 rows 3.808 -> 3.684,
   // 70B-AWQ at 13 rows 2.088 -> 2.085 (a 13-row tile is 19 % padding; the headline iteration measured 0.05 ms slower): stays row-major
-  if (off || ws->fused != 0 || tp_on(tp) || s->T > 64 || s->T < 16) return 0;
+  if (off || ws->fused == 1 || tp_on(tp) || s->T > 64 || s->T < 16) return 0;
   const int tt = umb_ll_token_tiles(s->T);
   if (tt < 1 || ws->Tmax < 16 * tt || m->H % 32 || m->I % 32 || (m->Hq * m->D) % 32) return 0;
   return tt;
@@ -152,7 +152,7 @@ static int layer_split(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
 // want a per-token factor in their epilogues (C3 / C4 iterations measured 1 % slower with it; the two regimes differ in their
 // int4 arithmetic anyway, so no invariance is lost across that boundary).
 static inline bool use_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const UmbTP* tp) {
-  return s->T <= 64 && ws->fused == 0 && ws->defer_norm && !tp_on(tp) && m->H % 512 == 0 && ws->ssq_stride >= m->H / 64 && ws->ssq_stride % 4 == 0 &&
+  return s->T <= 64 && ws->fused != 1 && ws->defer_norm && !tp_on(tp) && m->H % 512 == 0 && ws->ssq_stride >= m->H / 64 && ws->ssq_stride % 4 == 0 &&
          (m->H / 512) % 4 == 0;
 }
 static int prologue_defer(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s, const void* first_norm, int fm, int* groups,
@@ -246,7 +246,16 @@ static int layer_fused(const UmbModel* m, const UmbWorkspace* ws, const UmbStep*
 // Schedule 2 (low latency, T <= 64): 5 launches per layer, no cross-workgroup step at all.  Every GEMM workgroup owns
 // its output rows for the whole K (csrc/lowlat.hip) and runs the layer's elementwise work as its epilogue;
 // activations travel in FM (MFMA B-fragment) layout: ws->hw (K = H), ws->attn (K = Hq D), ws->act (K = I).
-static inline bool use_ll(const UmbWorkspace* ws, const UmbStep* s) { return ws->fused == 2 && s->T <= 64; }
+// A DRAFT-role model (its linears carry row-major copies: Llama.use_gemv) leaves the low-latency schedule from 16 rows on: there the
+// split schedule with FM operands and the deferred norm measured faster (1B forward, 16 / 32 rows: 0.843 / 0.915 ms vs 0.889 / 1.099;
+// 1 ... 8 rows: low-latency wins, 0.61-0.81 vs 0.78-0.83).  A draft only proposes, so its rows need not be the same bits at every row
+// count; targets keep ONE schedule for all <= 64-row forwards (speculative == autoregressive, bit for bit, rests on that).
+static inline bool use_ll(const UmbModel* m, const UmbWorkspace* ws, const UmbStep* s) {
+  if (ws->fused != 2 || s->T > 64) return false;
+  static const bool keep = getenv("UMB_LL_DRAFT_WIDE") != nullptr && getenv("UMB_LL_DRAFT_WIDE")[0] == '1';   // A/B
+  if (!keep && s->T >= 16 && s->layer_begin < s->layer_end && m->layers[s->layer_begin].qkv.w_rows) return false;
+  return true;
+}
 static inline int ll_groups(const UmbLinear& l) {
   int R, WN, WK, NW;
   umb_ll_plan(l.N, l.K, l.awq, &R, &WN, &WK, &NW);
@@ -521,7 +530,7 @@ static int model_forward(const UmbModel* m, const UmbWorkspace* ws, const UmbSte
     if (le == m->L) CK(head_gv(m, ws, s, groups, st));
     return UMB_OK;
   }
-  const bool ll = use_ll(ws, s);
+  const bool ll = use_ll(m, ws, s);
   const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
   const bool df = !ll && use_defer(m, ws, s, nullptr);
   int sg = 4;
@@ -603,7 +612,7 @@ extern "C" int umb_model_forward_offload(const UmbModel* m, const UmbWorkspace* 
   }
   if (pf) for (int i = 0; i < UMB_MAX_SLABS; ++i) pf[i] = -1;
 
-  const bool ll = use_ll(ws, s);
+  const bool ll = use_ll(m, ws, s);
   const int fm = ll ? 0 : split_fm_tt(m, ws, s, nullptr);
   const bool df = !ll && use_defer(m, ws, s, nullptr);
   int sg = 4;

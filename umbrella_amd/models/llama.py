@@ -603,7 +603,7 @@ class Llama(LLMBase):
         ws.fused = 2 if (self.sched == "ll" and not self.fused) else int(self.fused)
         # schedule 0 with the RMSNorm deferred (model.hip layer_split_defer): many-blocks-per-row residual reduces; UMB_DEFER_NORM=0:
         # the one-block-per-row reduce that normalises in place (A/B; tensor-parallel shards always take that one)
-        ws.defer_norm = int(ws.fused == 0 and os.environ.get("UMB_DEFER_NORM", "1") != "0")
+        ws.defer_norm = int(ws.fused != 1 and os.environ.get("UMB_DEFER_NORM", "1") != "0")
         if getattr(self, "chain", False):
             self._chain_setup()
 
