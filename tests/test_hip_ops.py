@@ -851,6 +851,52 @@ def test_verify_gemm_wide_full_width(dev, awq, T):
     assert float((y[:, :128] - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("T", [65, 80, 96, 111, 128, 143, 160, 176, 191, 208, 224, 239, 256, 257, 272, 288, 289, 300, 400, 577, 1000, 1024])
+def test_vgemm_w_every_instantiation_on_small_matrices(dev, T):
+    """csrc/vgemm.hip on small matrices (UMB_VGW_MIN_WGS=1 lets the 256-row kernel take them): every token-tile instantiation
+    (TT = 5 ... 18 through T = 65 ... 288, multi-chunk splits beyond), K slabs of ONE 128-k block, ragged splits (K = 384 at S = 2:
+    2 + 1 blocks), N = 256 ... 768, split-K partials and the fused SiLU epilogue with per-token 1/rms -- EVERY output against an fp32
+    matmul over the exactly dequantised fp16 weights (fp32 summation order is the only freedom)."""
+    from test_hip_engine import _awq_dequant_torch
+    from umbrella_amd import _lib
+    from umbrella_amd.models.llama import PackedLinear
+    from umbrella_amd.models.synthetic import synth_awq_tensors
+    lib = _lib.load()
+    dt = _lib.dtype_code(torch.float16)
+    os.environ["UMB_VGW_MIN_WGS"] = "1"
+    try:
+        for N, K, S, il in ((256, 128, 1, False), (512, 384, 2, False), (768, 1024, 3, False), (512, 512, 1, True)):
+            gen = torch.Generator(device=dev).manual_seed(T * 7 + N + K)
+            qw, qz, sc = synth_awq_tensors(N, K, 128, dev, gen)
+            lin = PackedLinear.from_awq(qw, qz, sc, interleave=il)
+            assert lib.umb_vgemm_w_ok(T, N, K, S, 2 if il else 0) == 1
+            x = (torch.randn(T + 3, K + 64, device=dev, generator=gen) * 0.5).half()[:T, :K]      # a strided view: ldx > K
+            wd = _awq_dequant_torch(qw, qz, sc).float()
+            ref = x.float() @ wd
+            if il:
+                G, stride = 8, 12
+                ssq = torch.rand(T, stride, device=dev, generator=gen) * 30 + 10
+                ssq[:, G:] = 1e9                                             # beyond the valid groups: must not be read
+                fx = _lib.UmbGemmFused()
+                fx.ssq_in, fx.ssq_groups, fx.pad0, fx.ssq_dim, fx.eps = ssq.data_ptr(), G, stride, float(K), 1e-5
+                act = torch.full((T, N // 2), float("nan"), dtype=torch.float16, device=dev)
+                _lib.call("umb_gemm_fused", act, x, x.stride(0), lin.w, lin.meta, T, N, K, 1, 1, lin.Rtb, 2, fx, dt)
+                inv = torch.rsqrt(ssq[:, :G].sum(1) / K + 1e-5)[:, None]
+                I = N // 2
+                gate, up = (ref[:, :I] * inv).half(), (ref[:, I:] * inv).half()
+                want = torch.nn.functional.silu(gate.float()).half().float() * up.float()
+                assert torch.isfinite(act).all()
+                assert float((act.float() - want).abs().max()) <= 8 * torch.finfo(torch.float16).eps * float(want.abs().max()) + 1e-6
+            else:
+                part = torch.full((S, T, N), float("nan"), dtype=torch.float32, device=dev)
+                _lib.call("umb_gemm", part, x, x.stride(0), lin.w, lin.meta, T, N, K, 1, S, lin.Rtb, 0, dt)
+                assert torch.isfinite(part).all()
+                y = part.sum(0)
+                assert float((y - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6, (N, K, S)
+    finally:
+        os.environ.pop("UMB_VGW_MIN_WGS", None)
+
+
 @pytest.mark.parametrize("T", [256, 257, 385, 769])
 @pytest.mark.parametrize("shape", ["qkv", "gu", "down"])
 def test_verify_gemm_wide_every_output_70b_shapes(dev, shape, T):

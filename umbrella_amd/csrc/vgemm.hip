@@ -356,6 +356,7 @@ static inline void vgw_shape(int T, int N, int S, int* nchunk, int* tt) {
       const long wgs = (long)(N / 256) * nc * S;
       const long rounds = (wgs + 255) / 256;
       const int ttc = (NT + nc - 1) / nc;
+      if (nc > nc0 && ttc < 5) break;                // the kernel is instantiated for 5 ... 18 token tiles
       // time ~ rounds x (tiles per chunk + a fixed per-workgroup cost worth ~1.5 tiles: prologue, epilogue, weight re-read)
       const double cost = (double)rounds * (ttc + 1.5);
       if (cost < best_cost - 1e-9) { best_cost = cost; best = nc; }
@@ -370,7 +371,10 @@ extern "C" int umb_vgemm_w_ok(int T, int N, int K, int S, int epi) {
   int nc, tt;
   vgw_shape(T, N, S, &nc, &tt);
   if (tt < 5) return 0;
-  return (N / 256) * nc * S >= 128;                // small layers keep the finer-grained kernels of gemm.hip
+  // small layers keep the finer-grained kernels of gemm.hip (UMB_VGW_MIN_WGS, read per call: tests drive every instantiation of
+  // this kernel on small matrices)
+  const char* mw = getenv("UMB_VGW_MIN_WGS");
+  return (N / 256) * nc * S >= (mw ? atoi(mw) : 128);
 }
 
 template <int TT>
