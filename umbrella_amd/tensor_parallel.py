@@ -410,7 +410,6 @@ class TensorParallelLlama:
             self.m._tp.peer = C.POINTER(_lib.UmbTPPeer)()
             self.peer.close()
             self.peer = None
-        self._hook_cb = getattr(self, "_hook_cb", None)  # (the ctypes callback stays referenced while the model struct lives)
 
     def peer_self_check(self, rows: int = 13, tol: float = 0.02, rounds: int = 3) -> bool:
         """The direct peer all-reduce has only ever run with the ranks on ONE device (where every rank shares an L2); on a
